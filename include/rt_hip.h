@@ -1,0 +1,209 @@
+/*
+ * rt_hip.h -- C ABI of libraytracing_amd.so: the HIP (gfx950) backend for the
+ * path-trace compute kernel and the scene model that feeds it.
+ *
+ * The reference has no FFI; its seam for this path is the C++ class boundary
+ * Engine -> ComputePipeline plus the shader's four descriptor bindings.  Each
+ * entry point below names the reference interface it stands in for
+ * (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative RT_E_* code on failure;
+ *     rt_last_error() returns the message of the calling thread's last failure
+ *     (the reference throws std::runtime_error(msg) instead:
+ *     src/engine/src/compute_pipeline.cpp:88-104, main.cpp:5-11);
+ *   - one rt_context per GPU, one in-order HIP stream per context, a context is
+ *     not thread-safe; host buffers passed in are copied before the call returns;
+ *   - there is no CPU fallback: without a HIP device rt_create fails.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+typedef struct rt_scene rt_scene;
+
+enum {
+    RT_OK = 0,
+    RT_E_INVALID = -1,  /* bad argument                              */
+    RT_E_HIP = -2,      /* a HIP runtime call failed                 */
+    RT_E_STATE = -3,    /* call order (e.g. dispatch before upload)  */
+    RT_E_IO = -4,       /* file could not be read or written         */
+    RT_E_PARSE = -5,    /* scene file does not match the schema      */
+    RT_E_NOMEM = -6
+};
+
+/* Meaning of every `a*b + c` in the shader source (GLSL leaves it open). */
+enum {
+    RT_PROFILE_STRICT = 0, /* multiply, round, add, round            */
+    RT_PROFILE_FUSED = 1   /* one fused multiply-add                 */
+};
+
+/* Which kernel runs a dispatch.  All give bit-identical images. */
+enum {
+    RT_KERNEL_STREAM = 0, /* persistent waves; a lane whose path ends takes the next pixel   */
+    RT_KERNEL_TILE = 1    /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
+};
+
+/* When the accumulation texel is zeroed. */
+enum {
+    RT_CLEAR_REFERENCE = 0, /* iff frameCount == 1 (res/shaders/shader.comp:79-81) */
+    RT_CLEAR_FIRST = 1,     /* before the first frame of a dispatch                */
+    RT_CLEAR_NEVER = 2
+};
+
+/* Layout of the records written by rt_trace_crop. */
+typedef struct rt_record {
+    int32_t hit;      /* sphere index, -1 = miss, -2 = bounce not reached */
+    uint32_t hash[3]; /* wang_hash(s), (s+1), (s+1920); 0 when hit < 0     */
+} rt_record;
+
+typedef struct rt_counters {
+    uint64_t rays;         /* Trace() calls (res/shaders/shader.comp:96) since the last reset */
+    uint64_t sphere_tests; /* rays x sphereCount                                                */
+    uint64_t paths;        /* pixel-frames rendered                                             */
+} rt_counters;
+
+/* ------------------------------------------------------------------ backend */
+
+/* ComputePipeline::ComputePipeline (src/engine/src/compute_pipeline.cpp:11-22):
+   selects the device, creates the stream and the W x H accumulation (rgba32f) and
+   colour (rgba8) images of createAccumulationImage (:178-269). */
+int rt_create(int device, int width, int height, rt_context** out);
+
+/* ComputePipeline::~ComputePipeline (compute_pipeline.cpp:24-50). */
+int rt_destroy(rt_context* ctx);
+
+/* ComputePipeline::windowResized (compute_pipeline.cpp:52-65): new accumulation
+   image of the new size, contents undefined until a clearing frame.  The caller
+   resets its frame counter, as the reference does at :64.  Buffers bound with
+   rt_bind_buffers are unbound. */
+int rt_resize(rt_context* ctx, int width, int height);
+
+/* Sphere half of ComputePipeline::updateScene (compute_pipeline.cpp:494-495):
+   `count` 32-byte AoS spheres (includes/scene.hpp:31-36) are copied and repacked
+   into the device geometry / albedo streams.  Call again only when spheres change. */
+int rt_upload_spheres(rt_context* ctx, const void* spheres_aos32, int count);
+
+/* UBO half of updateScene (compute_pipeline.cpp:492-493): the 80-byte
+   UniformBufferObject (includes/scene.hpp:22-29; sphereCount at byte 60,
+   frameCount at byte 64). */
+int rt_set_uniforms(rt_context* ctx, const void* ubo80);
+
+/* The literal 50 of res/shaders/shader.comp:95 as a parameter (default 50). */
+int rt_set_max_depth(rt_context* ctx, int max_depth);
+
+/* Float profile (default RT_PROFILE_STRICT) and kernel (default RT_KERNEL_STREAM). */
+int rt_set_profile(rt_context* ctx, int profile);
+int rt_set_kernel(rt_context* ctx, int kernel);
+
+/* Rows [row0,row1) of 8x8 tiles this context renders (screen-tile split across
+   GPUs); row1 <= 0 restores the whole image.  The reference always dispatches
+   floor(W/8) x floor(H/8) groups (compute_pipeline.cpp:429-432). */
+int rt_set_tile_rows(rt_context* ctx, int row0, int row1);
+
+/* Frame schedule of a multi-frame dispatch: frame j uses
+   frameCount = ubo.frameCount + j*stride (sample split across GPUs). */
+int rt_set_frame_schedule(rt_context* ctx, int frame_stride, int clear_mode);
+
+/* vkCmdDispatch of shader.comp main() (compute_pipeline.cpp:429-432), asynchronous
+   on the context's stream.  rt_dispatch_frames(n) gives the same bits as n
+   dispatches with frameCount, frameCount+stride, ... but keeps each texel in
+   registers across the n frames. */
+int rt_dispatch(rt_context* ctx);
+int rt_dispatch_frames(rt_context* ctx, int n_frames);
+
+/* vkWaitForFences of Engine::render (src/engine/engine.cpp:48). */
+int rt_sync(rt_context* ctx);
+
+/* Copies of binding 0 (rgba8, W*H*4 bytes) and binding 1 (rgba32f, W*H*16 bytes)
+   (res/shaders/shader.comp:6-7); both synchronise the stream first. */
+int rt_read_color(rt_context* ctx, uint8_t* rgba8);
+int rt_read_accum(rt_context* ctx, float* rgba32f);
+int rt_write_accum(rt_context* ctx, const float* rgba32f);
+
+/* Device addresses of the two images, for collectives that reduce or gather them
+   in place (no reference counterpart: the reference is single-GPU). */
+int rt_device_buffers(rt_context* ctx, void** accum_dev, void** color_dev);
+
+/* Use caller-owned device memory (W*H*16 / W*H*4 bytes) for the images; NULL
+   returns to the context's own allocations. */
+int rt_bind_buffers(rt_context* ctx, void* accum_dev, void* color_dev);
+
+/* Re-resolve the colour image from the accumulation image with an explicit
+   divisor: colour = unorm8(accum.rgb / divisor)  (shader.comp:129-132), used
+   after a cross-GPU sum. */
+int rt_resolve(rt_context* ctx, float divisor);
+
+/* Debug twin of rt_dispatch_frames for a crop: traces [x0,x0+w) x [y0,y0+h) and
+   writes n_frames*h*w*max_depth records (index ((j*h+y)*w+x)*max_depth+bounce) and,
+   if light is non-NULL, n_frames*h*w*3 floats of per-frame `light`.  Does not
+   touch the images. */
+int rt_trace_crop(rt_context* ctx, int n_frames, int x0, int y0, int w, int h,
+                  rt_record* records, float* light);
+
+int rt_get_counters(rt_context* ctx, rt_counters* out);
+int rt_reset_counters(rt_context* ctx);
+
+/* HIP-event timer on the context's stream: begin/end bracket any number of
+   dispatches; rt_timer_end synchronises and returns the elapsed milliseconds. */
+int rt_timer_begin(rt_context* ctx);
+int rt_timer_end(rt_context* ctx, float* ms);
+
+/* Launch geometry of the stream kernel (0 = choose from the device). */
+int rt_set_launch(rt_context* ctx, int blocks, int threads_per_block);
+int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* threads);
+
+/* Test hook: out[i] = op(a[i], b[i], c[i]) evaluated on the device with the kernels'
+   compile flags, so the parity tests can pin the GPU's float semantics against the
+   CPU's.  op: 0 sqrt(a), 1 a/b, 2 fma(a,b,c), 3 a*b+c in two roundings, 4 float(bits
+   of a as uint)/2^32, 5 1/sqrt(a), 6 unorm8(a) as bits, 7 wang_hash(bits of a) as bits.
+   No reference counterpart. */
+int rt_debug_math(rt_context* ctx, int op, const float* a, const float* b, const float* c,
+                  float* out, int n);
+
+const char* rt_last_error(void);
+
+/* -------------------------------------------------------------- scene model */
+
+/* Scene::Scene / Scene::reloadScene (src/scene.cpp:9-15,48-55): parse a scene
+   file in the reference's YAML schema (includes/scene.hpp:38-97).  sphereCount
+   comes from camera[4]; frameCount is forced to 0 (scene.hpp:75). */
+int rt_scene_load(const char* path, rt_scene** out);
+int rt_scene_parse(const char* text, size_t len, rt_scene** out);
+/* Scene::save (src/scene.cpp:57-72): block-style YAML, camera row position first. */
+int rt_scene_save(const rt_scene* scene, const char* path);
+int rt_scene_free(rt_scene* scene);
+
+/* Scene::spheres() / Scene::camera() (includes/scene.hpp:104-105). */
+int rt_scene_sphere_count(const rt_scene* scene);
+void* rt_scene_spheres(rt_scene* scene); /* count x 32 B, mutable like m_spheres */
+void* rt_scene_ubo(rt_scene* scene);     /* 80 B, mutable like m_camera           */
+
+/* The camera basis Application::Application installs at launch
+   (src/application.cpp:10-23) from yaw/pitch in degrees (scene.hpp:127-128). */
+int rt_scene_set_orientation(rt_scene* scene, float yaw_deg, float pitch_deg);
+
+/* Scene::update(dt) (includes/scene.hpp:106-116) and the keyboard impulse of
+   Application::handleInput (src/application.cpp:44-67): accel += dir * amount. */
+int rt_scene_update(rt_scene* scene, float dt);
+int rt_scene_add_acceleration(rt_scene* scene, float ax, float ay, float az);
+int rt_scene_reset_frame_count(rt_scene* scene); /* scene.hpp:118 */
+/* The public members Scene::acceleration / Scene::velocity (scene.hpp:125-126). */
+int rt_scene_get_motion(const rt_scene* scene, float acceleration[3], float velocity[3]);
+
+/* Seeded synthetic scenes written in the same schema.
+   kind 0: "rtiow"  -- ground + 22x22 jittered small spheres + 3 large ones;
+   kind 1: "cube"   -- `count` spheres with the distributions of src/scene.cpp:21-35. */
+int rt_scene_generate(int kind, int count, uint32_t seed, rt_scene** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

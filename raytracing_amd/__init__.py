@@ -1,0 +1,12 @@
+"""raytracing_amd: MI355X (gfx950) backend for the sphere path-tracer's compute kernel.
+
+The work is done by libraytracing_amd.so (HIP kernels behind the C ABI of
+include/rt_hip.h); this package is the thin Python host used by the tests and
+the benchmark.
+"""
+from .scene import Scene, SPHERE_DTYPE, UBO_DTYPE, DEFAULT_SCENE, KIND_RTIOW, KIND_CUBE  # noqa: F401
+from .renderer import (  # noqa: F401
+    Renderer, RECORD_DTYPE, PROFILE_STRICT, PROFILE_FUSED, KERNEL_STREAM, KERNEL_TILE,
+    CLEAR_REFERENCE, CLEAR_FIRST, CLEAR_NEVER,
+)
+from ._native import RtError  # noqa: F401

@@ -1,0 +1,601 @@
+// rt_api.cpp -- the rt_context half of the C ABI (include/rt_hip.h): device memory, the
+// geometry repack at upload, launch geometry and the dispatch entry points.  It stands in for
+// the reference's ComputePipeline (src/engine/src/compute_pipeline.cpp) without any of its
+// Vulkan objects: one HIP stream, four device buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_params.h"
+
+// launchers defined in rt_kernels.hip
+size_t rt_stream_lds_bytes(int n_pad, int threads);
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int blocks, int threads,
+                            hipStream_t st);
+hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
+hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
+                             int y1, float divisor, hipStream_t st);
+hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const float* c, float* out,
+                                int n, hipStream_t st);
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(RT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+}  // namespace
+
+void rt_set_error(const char* msg) { g_error = msg ? msg : ""; }
+
+struct rt_context {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int width = 0, height = 0;
+
+    float4* accum_own = nullptr;
+    uint32_t* color_own = nullptr;
+    float4* accum = nullptr;  // bound (own or caller's)
+    uint32_t* color = nullptr;
+
+    RtSphereAos* d_spheres = nullptr;  // AoS copy
+    float4* d_geom[2] = {nullptr, nullptr};  // pair-packed geometry per float profile
+    int n_spheres = 0;   // spheres in the buffer (Scene::spheres().size())
+    int sphere_cap = 0;  // allocated entries (multiple of RT_CHUNK)
+
+    unsigned* d_work = nullptr;           // 256-byte block; word 0 is the work counter
+    unsigned long long* d_rays = nullptr; // ray counter
+    uint64_t paths = 0;
+
+    unsigned char ubo[80] = {0};
+    bool have_ubo = false;
+    int max_depth = 50;
+    int profile = RT_PROFILE_STRICT;
+    int kernel = RT_KERNEL_STREAM;
+    int row0 = 0, row1 = 0;
+    int frame_stride = 1;
+    int clear_mode = RT_CLEAR_REFERENCE;
+    int blocks = 0, threads = 0;  // 0 = automatic
+};
+
+namespace {
+
+struct UboView {
+    float fwd[3], right[3], up[3], pos[3];
+    int sphere_count;
+    unsigned frame_count;
+};
+
+UboView read_ubo(const unsigned char* u)
+{
+    UboView v;
+    memcpy(v.fwd, u + 0, 12);
+    memcpy(v.right, u + 16, 12);
+    memcpy(v.up, u + 32, 12);
+    memcpy(v.pos, u + 48, 12);
+    memcpy(&v.sphere_count, u + 60, 4);
+    memcpy(&v.frame_count, u + 64, 4);
+    return v;
+}
+
+int free_images(rt_context* c)
+{
+    if (c->accum_own) HIP_TRY(hipFree(c->accum_own));
+    if (c->color_own) HIP_TRY(hipFree(c->color_own));
+    c->accum_own = nullptr;
+    c->color_own = nullptr;
+    return RT_OK;
+}
+
+int alloc_images(rt_context* c, int w, int h)
+{
+    const size_t px = (size_t)w * h;
+    HIP_TRY(hipMalloc(&c->accum_own, px * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->color_own, px * sizeof(uint32_t)));
+    // The reference leaves a new accumulation image undefined
+    // (compute_pipeline.cpp:178-269); zero is one legal instance of that.
+    HIP_TRY(hipMemsetAsync(c->accum_own, 0, px * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->color_own, 0, px * sizeof(uint32_t), c->stream));
+    c->accum = c->accum_own;
+    c->color = c->color_own;
+    c->width = w;
+    c->height = h;
+    return RT_OK;
+}
+
+// Fill the launch-independent part of the kernel arguments; validates state.
+int make_params(rt_context* c, int n_frames, RtParams* out)
+{
+    if (!c->have_ubo) return fail(RT_E_STATE, "rt_set_uniforms has not been called");
+    const UboView u = read_ubo(c->ubo);
+    if (u.sphere_count < 0 || u.sphere_count > c->n_spheres)
+        return fail(RT_E_INVALID, "ubo.sphereCount = %d but %d spheres are uploaded", u.sphere_count,
+                    c->n_spheres);
+    if (n_frames < 1) return fail(RT_E_INVALID, "n_frames must be >= 1 (got %d)", n_frames);
+    RtParams P;
+    memset(&P, 0, sizeof P);
+    memcpy(P.fwd, u.fwd, 12);
+    memcpy(P.right, u.right, 12);
+    memcpy(P.up, u.up, 12);
+    memcpy(P.pos, u.pos, 12);
+    P.sphere_count = u.sphere_count;
+    P.n_pad = (u.sphere_count + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
+    P.width = c->width;
+    P.height = c->height;
+    const int rows = c->height / 8;
+    const int r0 = std::max(0, c->row0);
+    const int r1 = (c->row1 > 0 && c->row1 < rows) ? c->row1 : rows;
+    P.tile_col0 = 0;
+    P.tile_cols = c->width / 8;
+    P.tile_row0 = r0;
+    P.tile_rows = std::max(0, r1 - r0);
+    P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
+    P.max_depth = c->max_depth;
+    P.frame0 = u.frame_count;
+    P.n_frames = n_frames;
+    P.frame_stride = c->frame_stride;
+    P.clear_mode = c->clear_mode;
+    P.spheres = c->d_spheres;
+    P.geom = c->d_geom[c->profile == RT_PROFILE_FUSED ? 1 : 0];
+    P.accum = c->accum;
+    P.color = c->color;
+    P.work_counter = c->d_work;
+    P.rays = c->d_rays;
+    *out = P;
+    return RT_OK;
+}
+
+// Workgroup size and count of the persistent kernel: aim for 16 waves per CU, bounded by the
+// LDS one workgroup needs (geometry + per-wave candidate masks).
+void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* threads)
+{
+    int t = c->threads > 0 ? c->threads : (P.n_pad <= 1024 ? 256 : 1024);
+    t = std::max(64, std::min(1024, t / 64 * 64));
+    const size_t lds = rt_stream_lds_bytes(P.n_pad, t);
+    int per_cu = std::min<int>(16 / (t / 64), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
+    per_cu = std::max(1, per_cu);
+    int b = c->blocks > 0 ? c->blocks : c->cu_count * per_cu;
+    const unsigned lanes_needed = (P.total_pixels + (unsigned)t - 1) / (unsigned)t;
+    b = (int)std::max(1u, std::min((unsigned)b, lanes_needed));
+    *blocks = b;
+    *threads = t;
+}
+
+int launch(rt_context* c, const RtParams& P, bool record)
+{
+    if (P.total_pixels == 0) return RT_OK;
+    const bool fused = c->profile == RT_PROFILE_FUSED;
+    const bool tile = c->kernel == RT_KERNEL_TILE || P.sphere_count > RT_MAX_LDS_SPHERES;
+    if (tile) {
+        HIP_TRY(rt_launch_tile(P, fused, record, c->stream));
+        return RT_OK;
+    }
+    int blocks, threads;
+    stream_geometry(c, P, &blocks, &threads);
+    if (rt_stream_lds_bytes(P.n_pad, threads) > kLdsPerCu)
+        return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
+    HIP_TRY(hipMemsetAsync(c->d_work, 0, 256, c->stream));
+    HIP_TRY(rt_launch_stream(P, fused, record, blocks, threads, c->stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_create(int device, int width, int height, rt_context** out)
+{
+    if (!out) return fail(RT_E_INVALID, "out is null");
+    *out = nullptr;
+    if (width <= 0 || height <= 0) return fail(RT_E_INVALID, "bad image size %dx%d", width, height);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RT_E_HIP, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(RT_E_INVALID, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    rt_context* c = new (std::nothrow) rt_context();
+    if (!c) return fail(RT_E_NOMEM, "out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(RT_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    c->cu_count = prop.multiProcessorCount;
+    auto bail = [&](int rc) {
+        rt_destroy(c);
+        return rc;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(RT_E_HIP, "hipStreamCreate failed"));
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+        return bail(fail(RT_E_HIP, "hipEventCreate failed"));
+    if (hipMalloc(&c->d_work, 256) != hipSuccess || hipMalloc(&c->d_rays, 256) != hipSuccess)
+        return bail(fail(RT_E_HIP, "hipMalloc failed"));
+    if (hipMemsetAsync(c->d_rays, 0, 256, c->stream) != hipSuccess)
+        return bail(fail(RT_E_HIP, "hipMemsetAsync failed"));
+    int rc = alloc_images(c, width, height);
+    if (rc != RT_OK) return bail(rc);
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context* c)
+{
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)free_images(c);
+    if (c->d_spheres) (void)hipFree(c->d_spheres);
+    if (c->d_geom[0]) (void)hipFree(c->d_geom[0]);
+    if (c->d_geom[1]) (void)hipFree(c->d_geom[1]);
+    if (c->d_work) (void)hipFree(c->d_work);
+    if (c->d_rays) (void)hipFree(c->d_rays);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_resize(rt_context* c, int width, int height)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (width <= 0 || height <= 0) return fail(RT_E_INVALID, "bad image size %dx%d", width, height);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // vkDeviceWaitIdle, compute_pipeline.cpp:53
+    int rc = free_images(c);
+    if (rc != RT_OK) return rc;
+    return alloc_images(c, width, height);  // also unbinds caller-owned buffers
+}
+
+int rt_upload_spheres(rt_context* c, const void* aos, int count)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (count < 0 || (count > 0 && !aos)) return fail(RT_E_INVALID, "bad sphere buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const int cap = std::max(RT_CHUNK, (count + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // no launch may still read the old buffers
+    if (cap > c->sphere_cap) {
+        if (c->d_spheres) HIP_TRY(hipFree(c->d_spheres));
+        if (c->d_geom[0]) HIP_TRY(hipFree(c->d_geom[0]));
+        if (c->d_geom[1]) HIP_TRY(hipFree(c->d_geom[1]));
+        c->d_spheres = nullptr;
+        c->d_geom[0] = c->d_geom[1] = nullptr;
+        c->sphere_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_spheres, (size_t)cap * sizeof(RtSphereAos)));
+        HIP_TRY(hipMalloc(&c->d_geom[0], (size_t)cap * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_geom[1], (size_t)cap * sizeof(float4)));
+        c->sphere_cap = cap;
+    }
+    // AoS copy (zero padded) + the two pair-packed geometry streams: for the pair (2k, 2k+1)
+    //   float4 {cx0, cx1, cy0, cy1}, float4 {cz0, cz1, w0, w1},
+    // w = -(r*r) for the STRICT profile and r for the FUSED one (dot(oc,oc) - r*r is
+    // dd + w resp. fma(-w, w, dd)).
+    std::vector<RtSphereAos> host(cap);
+    memset(host.data(), 0, host.size() * sizeof(RtSphereAos));
+    if (count) memcpy(host.data(), aos, (size_t)count * sizeof(RtSphereAos));
+    std::vector<float> g0((size_t)cap * 4), g1((size_t)cap * 4);
+    for (int i = 0; i < cap; i++) {
+        const RtSphereAos& s = host[i];
+        const size_t base = (size_t)(i >> 1) * 8 + (i & 1);
+        const float rr = s.radius * s.radius;
+        float* gs[2] = {g0.data(), g1.data()};
+        for (int m = 0; m < 2; m++) {
+            gs[m][base + 0] = s.cx;
+            gs[m][base + 2] = s.cy;
+            gs[m][base + 4] = s.cz;
+        }
+        g0[base + 6] = -rr;
+        g1[base + 6] = s.radius;
+    }
+    HIP_TRY(hipMemcpy(c->d_spheres, host.data(), (size_t)cap * sizeof(RtSphereAos), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_geom[0], g0.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_geom[1], g1.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
+    c->n_spheres = count;
+    return RT_OK;
+}
+
+int rt_set_uniforms(rt_context* c, const void* ubo80)
+{
+    if (!c || !ubo80) return fail(RT_E_INVALID, "null argument");
+    memcpy(c->ubo, ubo80, 80);
+    c->have_ubo = true;
+    return RT_OK;
+}
+
+int rt_set_max_depth(rt_context* c, int d)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (d < 1 || d > 65536) return fail(RT_E_INVALID, "max_depth %d out of range [1,65536]", d);
+    c->max_depth = d;
+    return RT_OK;
+}
+
+int rt_set_profile(rt_context* c, int profile)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (profile != RT_PROFILE_STRICT && profile != RT_PROFILE_FUSED)
+        return fail(RT_E_INVALID, "unknown float profile %d", profile);
+    c->profile = profile;
+    return RT_OK;
+}
+
+int rt_set_kernel(rt_context* c, int kernel)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (kernel != RT_KERNEL_STREAM && kernel != RT_KERNEL_TILE)
+        return fail(RT_E_INVALID, "unknown kernel %d", kernel);
+    c->kernel = kernel;
+    return RT_OK;
+}
+
+int rt_set_tile_rows(rt_context* c, int row0, int row1)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (row0 < 0 || (row1 > 0 && row1 < row0)) return fail(RT_E_INVALID, "bad tile rows [%d,%d)", row0, row1);
+    c->row0 = row0;
+    c->row1 = row1;
+    return RT_OK;
+}
+
+int rt_set_frame_schedule(rt_context* c, int stride, int clear_mode)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (stride < 1) return fail(RT_E_INVALID, "frame stride %d must be >= 1", stride);
+    if (clear_mode < RT_CLEAR_REFERENCE || clear_mode > RT_CLEAR_NEVER)
+        return fail(RT_E_INVALID, "unknown clear mode %d", clear_mode);
+    c->frame_stride = stride;
+    c->clear_mode = clear_mode;
+    return RT_OK;
+}
+
+int rt_set_launch(rt_context* c, int blocks, int threads)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (blocks < 0 || threads < 0 || threads > 1024 || (threads % 64) != 0)
+        return fail(RT_E_INVALID, "bad launch geometry %d x %d", blocks, threads);
+    c->blocks = blocks;
+    c->threads = threads;
+    return RT_OK;
+}
+
+int rt_get_info(rt_context* c, int* device, int* cu_count, int* blocks, int* threads)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (device) *device = c->device;
+    if (cu_count) *cu_count = c->cu_count;
+    int b = c->blocks, t = c->threads;
+    RtParams P;
+    if (c->have_ubo && make_params(c, 1, &P) == RT_OK) stream_geometry(c, P, &b, &t);
+    if (blocks) *blocks = b;
+    if (threads) *threads = t;
+    return RT_OK;
+}
+
+int rt_dispatch_frames(rt_context* c, int n_frames)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    RtParams P;
+    int rc = make_params(c, n_frames, &P);
+    if (rc != RT_OK) return rc;
+    rc = launch(c, P, false);
+    if (rc != RT_OK) return rc;
+    c->paths += (uint64_t)P.total_pixels * (uint64_t)n_frames;
+    return RT_OK;
+}
+
+int rt_dispatch(rt_context* c) { return rt_dispatch_frames(c, 1); }
+
+int rt_sync(rt_context* c)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_color(rt_context* c, uint8_t* rgba8)
+{
+    if (!c || !rgba8) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(rgba8, c->color, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_accum(rt_context* c, float* rgba32f)
+{
+    if (!c || !rgba32f) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(rgba32f, c->accum, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_write_accum(rt_context* c, const float* rgba32f)
+{
+    if (!c || !rgba32f) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->accum, rgba32f, (size_t)c->width * c->height * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_device_buffers(rt_context* c, void** accum_dev, void** color_dev)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (accum_dev) *accum_dev = c->accum;
+    if (color_dev) *color_dev = c->color;
+    return RT_OK;
+}
+
+int rt_bind_buffers(rt_context* c, void* accum_dev, void* color_dev)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->accum = accum_dev ? static_cast<float4*>(accum_dev) : c->accum_own;
+    c->color = color_dev ? static_cast<uint32_t*>(color_dev) : c->color_own;
+    return RT_OK;
+}
+
+int rt_resolve(rt_context* c, float divisor)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    const int rows = c->height / 8;
+    const int r0 = std::max(0, c->row0);
+    const int r1 = (c->row1 > 0 && c->row1 < rows) ? c->row1 : rows;
+    HIP_TRY(rt_launch_resolve(c->accum, c->color, c->width, (c->width / 8) * 8, r0 * 8, r1 * 8, divisor,
+                              c->stream));
+    return RT_OK;
+}
+
+int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_record* records,
+                  float* light)
+{
+    if (!c || !records) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    RtParams P;
+    int rc = make_params(c, n_frames, &P);
+    if (rc != RT_OK) return rc;
+    const int xmax = (c->width / 8) * 8, ymax = (c->height / 8) * 8;
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > xmax || y0 + h > ymax)
+        return fail(RT_E_INVALID, "crop [%d,%d)+(%d,%d) outside the rendered %dx%d", x0, y0, w, h, xmax, ymax);
+    // tile-aligned bounding box of the crop
+    P.tile_col0 = x0 / 8;
+    P.tile_cols = (x0 + w + 7) / 8 - P.tile_col0;
+    P.tile_row0 = y0 / 8;
+    P.tile_rows = (y0 + h + 7) / 8 - P.tile_row0;
+    P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
+    P.rec_x0 = x0;
+    P.rec_y0 = y0;
+    P.rec_w = w;
+    P.rec_h = h;
+    const size_t npix = (size_t)n_frames * w * h;
+    const size_t nrec = npix * (size_t)c->max_depth;
+    std::vector<rt_record> init(nrec);
+    for (auto& r : init) {
+        r.hit = -2;
+        r.hash[0] = r.hash[1] = r.hash[2] = 0;
+    }
+    rt_record* d_rec = nullptr;
+    float* d_light = nullptr;
+    HIP_TRY(hipMalloc(&d_rec, nrec * sizeof(rt_record)));
+    hipError_t e = hipMemcpy(d_rec, init.data(), nrec * sizeof(rt_record), hipMemcpyHostToDevice);
+    if (e == hipSuccess && light) e = hipMalloc(&d_light, npix * 3 * sizeof(float));
+    if (e == hipSuccess && light) e = hipMemset(d_light, 0, npix * 3 * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(d_rec);
+        if (d_light) (void)hipFree(d_light);
+        return fail(RT_E_HIP, "record buffer setup: %s", hipGetErrorString(e));
+    }
+    P.records = d_rec;
+    P.rec_light = d_light;
+    rc = launch(c, P, true);
+    if (rc == RT_OK) {
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(records, d_rec, nrec * sizeof(rt_record), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && light) e = hipMemcpy(light, d_light, npix * 3 * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_E_HIP, "record readback: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_rec);
+    if (d_light) (void)hipFree(d_light);
+    return rc;
+}
+
+int rt_get_counters(rt_context* c, rt_counters* out)
+{
+    if (!c || !out) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long rays = 0;
+    HIP_TRY(hipMemcpyAsync(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int count = 0;
+    if (c->have_ubo) memcpy(&count, c->ubo + 60, 4);
+    out->rays = rays;
+    out->sphere_tests = rays * (uint64_t)std::max(0, count);
+    out->paths = c->paths;
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_context* c)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_rays, 0, 256, c->stream));
+    c->paths = 0;
+    return RT_OK;
+}
+
+int rt_timer_begin(rt_context* c)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return RT_OK;
+}
+
+int rt_timer_end(rt_context* c, float* ms)
+{
+    if (!c || !ms) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RT_OK;
+}
+
+// Device arithmetic probe for the parity tests: out[i] = op(a[i], b[i], c[i]) evaluated on the
+// GPU with the kernels' compile flags (0 sqrt, 1 divide, 2 fma, 3 mul-then-add, 4 hash->float,
+// 5 1/sqrt, 6 unorm8, 7 wang_hash on the bit pattern).
+int rt_debug_math(rt_context* c, int op, const float* a, const float* b, const float* cc, float* out, int n)
+{
+    if (!c || !a || !b || !cc || !out || n <= 0) return fail(RT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    HIP_TRY(hipMalloc(&d, 4 * bytes));
+    hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * (size_t)n, cc, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt_launch_math_probe(op, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_E_HIP, "math probe: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,572 @@
+// rt_kernels.hip -- the path-trace kernels for gfx950 (CDNA4, wave64).
+//
+// What is computed is the reference compute shader, res/shaders/shader.comp:72-133
+// with the RNG of res/shaders/def.glsl:40-62: per pixel and frame one camera ray,
+// up to max_depth brute-force nearest-hit searches over the sphere list, a tinted
+// near-mirror bounce, and a float4 accumulate + rgba8 resolve.
+//
+// Build with -ffp-contract=off: the only fused multiply-adds are the explicit ones of
+// the FUSED float profile, so every result is reproducible bit for bit on the CPU.
+//
+// Two kernels, same results:
+//   rt_tile_kernel   one wave per 8x8 tile, one lane per pixel, the sphere loop exactly as
+//                    the shader writes it.  The plain mapping, kept as the in-GPU cross-check.
+//   rt_stream_kernel persistent waves.  A lane whose path (or pixel) has ended takes the next
+//                    pixel from a shared counter, so all 64 lanes carry a live ray in almost
+//                    every pass over the spheres, whatever the spread of bounce counts.  The
+//                    sphere loop is split in two:
+//                      sieve: for 32 spheres at a time, packed-f32 math on sphere PAIRS computes
+//                             q = s*s - a*c (disc = 4q) and shifts its sign bit into a per-lane
+//                             mask: 6 packed ops + 1 shift per ray-sphere test, no branch;
+//                      walk : each lane then visits only its own candidates (q >= 0) in index
+//                             order and evaluates the shader's expressions literally
+//                             (sqrt, divide, t > 0, t < best), so ties and rounding are the
+//                             shader's.
+//                    Geometry is staged once per workgroup in LDS as pair-packed float4s and read
+//                    with wave-uniform (broadcast) ds_read_b128.
+#include <hip/hip_runtime.h>
+
+#include "rt_params.h"
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define RT_FLT_MAX 3.402823466e+38f  // def.glsl:27
+
+// ----------------------------------------------------------------- arithmetic
+
+// The shader's `a*b + c` under the two float profiles.
+template <bool FUSED>
+__device__ __forceinline__ float mad(float a, float b, float c)
+{
+    if constexpr (FUSED)
+        return __builtin_fmaf(a, b, c);
+    else
+        return a * b + c;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ v2f mad2(v2f a, v2f b, v2f c)
+{
+    if constexpr (FUSED)
+        return __builtin_elementwise_fma(a, b, c);
+    else
+        return a * b + c;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return mad<FUSED>(az, bz, mad<FUSED>(ay, by, ax * bx));
+}
+
+// def.glsl:40-48
+__device__ __forceinline__ uint32_t wang_hash(uint32_t seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+
+// def.glsl:52-54: the row stride is the literal 1920 whatever the image width.
+__device__ __forceinline__ uint32_t rng_seed(uint32_t px, uint32_t py, uint32_t frame, uint32_t bounce)
+{
+    return px + 1920u * py + frame * (1920u * 1080u) + bounce * (1920u * 1080u * 256u);
+}
+
+// def.glsl:55: v_cvt_f32_u32 rounds to nearest even; the scale by 2^-32 is exact.
+__device__ __forceinline__ float hash_to_float(uint32_t h)
+{
+    return (float)h * 2.3283064365386963e-10f;
+}
+
+// rgba8 image store of shader.comp:132.
+__device__ __forceinline__ uint32_t unorm8(float v)
+{
+    if (!(v > 0.0f)) return 0u;
+    if (v > 1.0f) v = 1.0f;
+    return (uint32_t)floorf(v * 255.0f + 0.5f);
+}
+
+__device__ __forceinline__ bool clear_at(const RtParams& P, int j, uint32_t frame)
+{
+    return P.clear_mode == RT_CLEAR_REFERENCE ? frame == 1u
+         : P.clear_mode == RT_CLEAR_FIRST     ? j == 0
+                                              : false;
+}
+
+// ----------------------------------------------------------------- path state
+
+struct Path {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float cr, cg, cb;  // contribution
+    float lr, lg, lb;  // light
+    int bounce;
+};
+
+// shader.comp:73-76,82-94: primary ray of pixel (px,py).
+template <bool FUSED>
+__device__ __forceinline__ void path_begin(Path& p, const RtParams& P, uint32_t px, uint32_t py)
+{
+    const float fw = (float)P.width;
+    const float hc = ((float)px * 2.0f - fw) / fw;
+    const float vc = ((float)py * 2.0f - (float)P.height) / fw;  // divides by WIDTH
+    const float x = mad<FUSED>(vc, P.up[0], mad<FUSED>(hc, P.right[0], P.fwd[0]));
+    const float y = mad<FUSED>(vc, P.up[1], mad<FUSED>(hc, P.right[1], P.fwd[1]));
+    const float z = mad<FUSED>(vc, P.up[2], mad<FUSED>(hc, P.right[2], P.fwd[2]));
+    const float inv = 1.0f / sqrtf(dot3<FUSED>(x, y, z, x, y, z));
+    p.ox = P.pos[0]; p.oy = P.pos[1]; p.oz = P.pos[2];
+    p.dx = x * inv; p.dy = y * inv; p.dz = z * inv;
+    p.cr = p.cg = p.cb = 0.15f;
+    p.lr = p.lg = p.lb = 0.0f;
+    p.bounce = 0;
+}
+
+// shader.comp:97-118 after one Trace(): returns true when the path has ended.
+// idx/t are the nearest hit (idx < 0: miss).
+template <bool FUSED, bool RECORD>
+__device__ __forceinline__ bool path_bounce(Path& p, const RtParams& P, int idx, float t,
+                                            uint32_t px, uint32_t py, uint32_t frame,
+                                            rt_record* rec)
+{
+    if (idx < 0) {
+        p.lr = mad<FUSED>(0.6f, p.cr, p.lr);  // light += sky_color * contribution
+        p.lg = mad<FUSED>(0.7f, p.cg, p.lg);
+        p.lb = mad<FUSED>(0.9f, p.cb, p.lb);
+        if constexpr (RECORD) if (rec) rec[p.bounce].hit = -1;
+        return true;
+    }
+    const float4* sp = reinterpret_cast<const float4*>(P.spheres + idx);
+    const float4 g = sp[0];   // centre, radius
+    const float4 col = sp[1]; // albedo
+
+    // shader.comp:56-57 for the winning sphere
+    const float hx = mad<FUSED>(t, p.dx, p.ox);
+    const float hy = mad<FUSED>(t, p.dy, p.oy);
+    const float hz = mad<FUSED>(t, p.dz, p.oz);
+    const float pcx = hx - g.x, pcy = hy - g.y, pcz = hz - g.z;
+    const float ninv = 1.0f / sqrtf(dot3<FUSED>(pcx, pcy, pcz, pcx, pcy, pcz));
+    const float nx = pcx * ninv, ny = pcy * ninv, nz = pcz * ninv;
+
+    const uint32_t s = rng_seed(px, py, frame, (uint32_t)p.bounce);
+    const uint32_t h0 = wang_hash(s), h1 = wang_hash(s + 1u), h2 = wang_hash(s + 1920u);
+    if constexpr (RECORD) if (rec) {
+        rec[p.bounce].hit = idx;
+        rec[p.bounce].hash[0] = h0;
+        rec[p.bounce].hash[1] = h1;
+        rec[p.bounce].hash[2] = h2;
+    }
+    const float r0 = hash_to_float(h0), r1 = hash_to_float(h1), r2 = hash_to_float(h2);
+    const float rough = mad<FUSED>(r0, 0.02f - 0.0f, 0.0f);  // shader.comp:105
+
+    p.cr *= col.x; p.cg *= col.y; p.cb *= col.z;  // :109
+    if (idx <= 2) {                               // :110-112 (idx >= 0 here)
+        p.lr = mad<FUSED>(2.0f, col.x, p.lr);
+        p.lg = mad<FUSED>(2.0f, col.y, p.lg);
+        p.lb = mad<FUSED>(2.0f, col.z, p.lb);
+    }
+    p.ox = mad<FUSED>(nx, 0.0001f, hx);           // :115
+    p.oy = mad<FUSED>(ny, 0.0001f, hy);
+    p.oz = mad<FUSED>(nz, 0.0001f, hz);
+
+    const float vx = mad<FUSED>(r0, 2.0f, -1.0f), vy = mad<FUSED>(r1, 2.0f, -1.0f),
+                vz = mad<FUSED>(r2, 2.0f, -1.0f);
+    const float vinv = 1.0f / sqrtf(dot3<FUSED>(vx, vy, vz, vx, vy, vz));
+    const float npx = mad<FUSED>(rough, vx * vinv, nx);  // :118 normal, not unit length
+    const float npy = mad<FUSED>(rough, vy * vinv, ny);
+    const float npz = mad<FUSED>(rough, vz * vinv, nz);
+    const float k2 = 2.0f * dot3<FUSED>(npx, npy, npz, p.dx, p.dy, p.dz);
+    p.dx = mad<FUSED>(-k2, npx, p.dx);                   // reflect(); not re-normalised
+    p.dy = mad<FUSED>(-k2, npy, p.dy);
+    p.dz = mad<FUSED>(-k2, npz, p.dz);
+
+    p.bounce++;
+    return p.bounce >= P.max_depth;
+}
+
+// shader.comp:44-60 for one sphere, literally.  w is the radius (FUSED) or -(r*r) (STRICT).
+template <bool FUSED>
+__device__ __forceinline__ void test_sphere(const Path& p, float a, float cx, float cy, float cz,
+                                            float w, int i, float& best, int& idx)
+{
+    const float ocx = p.ox - cx, ocy = p.oy - cy, ocz = p.oz - cz;
+    const float b = 2.0f * dot3<FUSED>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
+    const float dd = dot3<FUSED>(ocx, ocy, ocz, ocx, ocy, ocz);
+    float c;
+    if constexpr (FUSED)
+        c = __builtin_fmaf(-w, w, dd);  // dot(oc,oc) - r*r
+    else
+        c = dd + w;
+    const float disc = mad<FUSED>(b, b, -((4.0f * a) * c));
+    if (!(disc < 0.0f)) {
+        const float t = (-b - sqrtf(disc)) / (2.0f * a);
+        if (t > 0.0f && t < best) {
+            best = t;
+            idx = i;
+        }
+    }
+}
+
+__device__ __forceinline__ rt_record* record_slot(const RtParams& P, uint32_t px, uint32_t py, int j)
+{
+    const int rx = (int)px - P.rec_x0, ry = (int)py - P.rec_y0;
+    if (rx < 0 || ry < 0 || rx >= P.rec_w || ry >= P.rec_h) return nullptr;
+    const size_t pix = ((size_t)j * P.rec_h + ry) * P.rec_w + rx;
+    return P.records + pix * (size_t)P.max_depth;
+}
+
+__device__ __forceinline__ void record_light(const RtParams& P, uint32_t px, uint32_t py, int j,
+                                             const Path& p)
+{
+    const int rx = (int)px - P.rec_x0, ry = (int)py - P.rec_y0;
+    if (!P.rec_light || rx < 0 || ry < 0 || rx >= P.rec_w || ry >= P.rec_h) return;
+    const size_t pix = ((size_t)j * P.rec_h + ry) * P.rec_w + rx;
+    P.rec_light[3 * pix + 0] = p.lr;
+    P.rec_light[3 * pix + 1] = p.lg;
+    P.rec_light[3 * pix + 2] = p.lb;
+}
+
+// shader.comp:126-132 for the last frame of a dispatch.
+__device__ __forceinline__ void store_pixel(const RtParams& P, uint32_t px, uint32_t py, float4 acc)
+{
+    const size_t at = (size_t)py * P.width + px;
+    P.accum[at] = acc;
+    const uint32_t last = P.frame0 + (uint32_t)((P.n_frames - 1) * P.frame_stride);
+    const float div = (float)(int)(last + 1u);
+    P.color[at] = unorm8(acc.x / div) | (unorm8(acc.y / div) << 8) | (unorm8(acc.z / div) << 16) |
+                  0xff000000u;
+}
+
+__device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+__device__ __forceinline__ void add_rays(const RtParams& P, unsigned nrays)
+{
+    unsigned long long v = nrays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(P.rays, v);
+}
+
+// ---------------------------------------------------------------- tile kernel
+
+// One wave per 8x8 tile (the shader's local_size, shader.comp:2), one lane per pixel, the
+// sphere loop as written.  grid = (tile_cols, tile_rows).
+template <bool FUSED, bool RECORD>
+__global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
+{
+    const uint32_t px = (uint32_t)(P.tile_col0 + (int)blockIdx.x) * 8 + (threadIdx.x & 7);
+    const uint32_t py = (uint32_t)(P.tile_row0 + (int)blockIdx.y) * 8 + (threadIdx.x >> 3);
+    const size_t at = (size_t)py * P.width + px;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!RECORD)
+        if (!clear_at(P, 0, P.frame0)) acc = P.accum[at];
+    unsigned nrays = 0;
+
+    for (int j = 0; j < P.n_frames; j++) {
+        const uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
+        if (j > 0 && clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        rt_record* rec = nullptr;
+        if constexpr (RECORD) rec = record_slot(P, px, py, j);
+        Path p;
+        path_begin<FUSED>(p, P, px, py);
+        bool alive = true;
+        // per-wavefront bounce termination: the wave leaves when its last path has ended
+        while (__ballot(alive) != 0ull) {
+            const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+            float best = RT_FLT_MAX;
+            int idx = -1;
+            for (int i = 0; i < P.sphere_count; i++) {
+                const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
+                float w;
+                if constexpr (FUSED) w = g.w; else w = -(g.w * g.w);
+                test_sphere<FUSED>(p, a, g.x, g.y, g.z, w, i, best, idx);
+            }
+            if (alive) {
+                nrays++;
+                if (path_bounce<FUSED, RECORD>(p, P, idx, best, px, py, frame, rec)) alive = false;
+            }
+        }
+        if constexpr (RECORD) record_light(P, px, py, j, p);
+        acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
+        acc.y = p.lg + acc.y;
+        acc.z = p.lb + acc.z;
+        acc.w = 1.0f + acc.w;
+    }
+    if constexpr (!RECORD) {
+        store_pixel(P, px, py, acc);
+        add_rays(P, nrays);
+    }
+}
+
+// -------------------------------------------------------------- stream kernel
+
+// Sieve of one chunk (32 spheres = 16 pairs).  g points at the chunk's 32 float4s in LDS:
+// pair k is {cx0,cx1,cy0,cy1}, {cz0,cz1,w0,w1}.  Returns a mask whose bit (31-n) is SET when
+// sphere n of the chunk is rejected (q < 0): the sign bit of q is shifted in from the right,
+// sphere 0 first.
+template <bool FUSED>
+__device__ __forceinline__ uint32_t sieve_chunk(const float4* g, v2f ox, v2f oy, v2f oz, v2f dx,
+                                                v2f dy, v2f dz, v2f a)
+{
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < RT_CHUNK / 2; k++) {
+        const float4 A = g[2 * k], B = g[2 * k + 1];
+        const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, w = {B.z, B.w};
+        const v2f ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+        const v2f s = mad2<FUSED>(ocz, dz, mad2<FUSED>(ocy, dy, ocx * dx));      // dot(oc, d)
+        const v2f dd = mad2<FUSED>(ocz, ocz, mad2<FUSED>(ocy, ocy, ocx * ocx));  // dot(oc, oc)
+        v2f c;
+        if constexpr (FUSED)
+            c = __builtin_elementwise_fma(-w, w, dd);
+        else
+            c = dd + w;
+        // disc = b*b - 4*a*c with b = 2s is exactly 4*(s*s - a*c): scaling by 2 and 4 commutes
+        // with rounding, so q has the sign of the shader's discriminant.
+        const v2f q = mad2<FUSED>(s, s, -(a * c));
+        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x), 31);
+        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y), 31);
+    }
+    return mask;
+}
+
+// Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
+// n_pad*16 B geometry + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B candidate masks.
+template <bool FUSED, bool RECORD>
+__global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
+{
+    extern __shared__ float4 smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) smem[i] = P.geom[i];
+    __syncthreads();  // the only barrier: waves run independently from here on
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(smem + P.n_pad) + wave * (RT_SG_CHUNKS * 64);
+    const float* gf = reinterpret_cast<const float*>(smem);
+    const int nch = P.n_pad / RT_CHUNK;
+
+    // wave-uniform work span
+    uint32_t span_cur = 0, span_end = 0;
+    bool exhausted = false;
+
+    // lane state
+    bool alive = false, start = false;
+    uint32_t px = 0, py = 0, frame = 0;
+    int j = 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned nrays = 0;
+    rt_record* rec = nullptr;
+    Path p;
+    p.ox = p.oy = p.oz = 0.f; p.dx = p.dy = p.dz = 0.f;
+    p.cr = p.cg = p.cb = 0.f; p.lr = p.lg = p.lb = 0.f; p.bounce = 0;
+
+    for (;;) {
+        // ---- refill: free lanes take the next pixels of the wave's span
+        unsigned long long freem = __ballot(!alive);
+        while (freem != 0ull && !exhausted) {
+            if (span_cur == span_end) {
+                uint32_t s0 = 0;
+                if (lane == 0) s0 = atomicAdd(P.work_counter, RT_SPAN);
+                s0 = __builtin_amdgcn_readfirstlane(s0);
+                if (s0 >= P.total_pixels) {
+                    exhausted = true;
+                    break;
+                }
+                span_cur = s0;
+                span_end = min(s0 + RT_SPAN, P.total_pixels);
+            }
+            const uint32_t navail = span_end - span_cur;
+            const uint32_t rank = mbcnt64(freem);
+            if (!alive && rank < navail) {
+                const uint32_t pix = span_cur + rank;
+                const uint32_t tile = pix >> 6, l = pix & 63u;
+                const uint32_t ty = tile / (uint32_t)P.tile_cols, tx = tile - ty * (uint32_t)P.tile_cols;
+                px = ((uint32_t)P.tile_col0 + tx) * 8 + (l & 7u);
+                py = ((uint32_t)P.tile_row0 + ty) * 8 + (l >> 3);
+                j = 0;
+                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (!RECORD)
+                    if (!clear_at(P, 0, P.frame0)) acc = P.accum[(size_t)py * P.width + px];
+                alive = true;
+                start = true;
+            }
+            span_cur += min((uint32_t)__popcll(freem), navail);
+            freem = __ballot(!alive);
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- a lane at the start of a path generates its camera ray
+        if (start) {
+            frame = P.frame0 + (uint32_t)(j * P.frame_stride);
+            if (j > 0 && clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (RECORD) rec = record_slot(P, px, py, j);
+            path_begin<FUSED>(p, P, px, py);
+            start = false;
+        }
+
+        // ---- Trace(): sieve + candidate walk
+        const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+        float best = RT_FLT_MAX;
+        int idx = -1;
+        {
+            const v2f ox = {p.ox, p.ox}, oy = {p.oy, p.oy}, oz = {p.oz, p.oz};
+            const v2f dx = {p.dx, p.dx}, dy = {p.dy, p.dy}, dz = {p.dz, p.dz};
+            const v2f a2 = {a, a};
+            for (int sg = 0; sg < nch; sg += RT_SG_CHUNKS) {
+                const int nsg = min(RT_SG_CHUNKS, nch - sg);
+                uint32_t summary = 0;
+                for (int c = 0; c < nsg; c++) {
+                    const uint32_t rej =
+                        sieve_chunk<FUSED>(smem + (sg + c) * RT_CHUNK, ox, oy, oz, dx, dy, dz, a2);
+                    // bits of padding spheres beyond sphere_count are never candidates
+                    const int nvalid = min(RT_CHUNK, max(0, P.sphere_count - (sg + c) * RT_CHUNK));
+                    const uint32_t valid = nvalid >= 32 ? 0xffffffffu : ~(0xffffffffu >> nvalid);
+                    const uint32_t cand = alive ? (~rej & valid) : 0u;
+                    wmask[c * 64 + lane] = cand;
+                    summary = (summary << 1) | (cand != 0u ? 1u : 0u);
+                }
+                summary <<= (32 - nsg);
+                // walk: every lane visits its own candidates in increasing sphere index
+                uint32_t cur = 0;
+                int curbase = 0;
+                for (;;) {
+                    if (cur == 0u && summary != 0u) {
+                        const int k = __clz(summary);
+                        summary &= ~(0x80000000u >> k);
+                        cur = wmask[k * 64 + lane];
+                        curbase = (sg + k) * RT_CHUNK;
+                    }
+                    if (__ballot(cur != 0u) == 0ull) break;
+                    if (cur != 0u) {
+                        const int b = __clz(cur);
+                        cur &= ~(0x80000000u >> b);
+                        const int i = curbase + b;
+                        const float* f = gf + (i >> 1) * 8 + (i & 1);
+                        test_sphere<FUSED>(p, a, f[0], f[2], f[4], f[6], i, best, idx);
+                    }
+                }
+            }
+        }
+
+        // ---- shade
+        if (alive) {
+            nrays++;
+            if (path_bounce<FUSED, RECORD>(p, P, idx, best, px, py, frame, rec)) {
+                if constexpr (RECORD) record_light(P, px, py, j, p);
+                acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
+                acc.y = p.lg + acc.y;
+                acc.z = p.lb + acc.z;
+                acc.w = 1.0f + acc.w;
+                j++;
+                if (j == P.n_frames) {
+                    if constexpr (!RECORD) store_pixel(P, px, py, acc);
+                    alive = false;
+                } else {
+                    start = true;
+                }
+            }
+        }
+    }
+    if constexpr (!RECORD) add_rays(P, nrays);
+}
+
+// ------------------------------------------------------------------- resolve
+
+// colour = unorm8(accum.rgb / divisor) over the rendered region (shader.comp:129-132).
+__global__ void rt_resolve_kernel(const float4* accum, uint32_t* color, int width, int x_max,
+                                  int y0, int y1, float divisor)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = y0 + blockIdx.y;
+    if (x >= x_max || y >= y1) return;
+    const size_t at = (size_t)y * width + x;
+    const float4 a = accum[at];
+    color[at] = unorm8(a.x / divisor) | (unorm8(a.y / divisor) << 8) | (unorm8(a.z / divisor) << 16) |
+                0xff000000u;
+}
+
+// ---------------------------------------------------------------- math probe
+
+// Device arithmetic exposed for the parity tests: out[i] = op(a[i], b[i], c[i]).
+__global__ void rt_math_probe_kernel(int op, const float* a, const float* b, const float* c,
+                                     float* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.f;
+    switch (op) {
+        case 0: r = sqrtf(a[i]); break;
+        case 1: r = a[i] / b[i]; break;
+        case 2: r = __builtin_fmaf(a[i], b[i], c[i]); break;
+        case 3: r = a[i] * b[i] + c[i]; break;  // must stay two roundings
+        case 4: r = hash_to_float(__float_as_uint(a[i])); break;
+        case 5: r = 1.0f / sqrtf(a[i]); break;
+        case 6: r = __uint_as_float(unorm8(a[i])); break;
+        case 7: r = __uint_as_float(wang_hash(__float_as_uint(a[i]))); break;
+    }
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------ launchers
+
+template <bool FUSED, bool RECORD>
+static hipError_t launch_stream(const RtParams& P, int blocks, int threads, size_t lds, hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((rt_stream_kernel<FUSED, RECORD>), dim3(blocks), dim3(threads), lds, st, P);
+    return hipGetLastError();
+}
+
+template <bool FUSED, bool RECORD>
+static hipError_t launch_tile(const RtParams& P, hipStream_t st)
+{
+    hipLaunchKernelGGL((rt_tile_kernel<FUSED, RECORD>), dim3(P.tile_cols, P.tile_rows), dim3(64), 0, st, P);
+    return hipGetLastError();
+}
+
+size_t rt_stream_lds_bytes(int n_pad, int threads)
+{
+    return (size_t)n_pad * sizeof(float4) + (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
+}
+
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int blocks, int threads,
+                            hipStream_t st)
+{
+    const size_t lds = rt_stream_lds_bytes(P.n_pad, threads);
+    if (fused)
+        return record ? launch_stream<true, true>(P, blocks, threads, lds, st)
+                      : launch_stream<true, false>(P, blocks, threads, lds, st);
+    return record ? launch_stream<false, true>(P, blocks, threads, lds, st)
+                  : launch_stream<false, false>(P, blocks, threads, lds, st);
+}
+
+hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st)
+{
+    if (fused) return record ? launch_tile<true, true>(P, st) : launch_tile<true, false>(P, st);
+    return record ? launch_tile<false, true>(P, st) : launch_tile<false, false>(P, st);
+}
+
+hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
+                             int y1, float divisor, hipStream_t st)
+{
+    if (x_max <= 0 || y1 <= y0) return hipSuccess;
+    dim3 grid((x_max + 255) / 256, y1 - y0);
+    hipLaunchKernelGGL(rt_resolve_kernel, grid, dim3(256), 0, st, accum, color, width, x_max, y0, y1,
+                       divisor);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const float* c, float* out,
+                                int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(rt_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, op, a, b, c, out, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,52 @@
+// rt_params.h -- kernel argument block shared by the host API and the HIP kernels.
+#pragma once
+
+#include <stdint.h>
+
+#include "rt_hip.h"
+
+// 32-byte AoS sphere exactly as the host hands it over
+// (reference includes/scene.hpp:31-36, res/shaders/def.glsl:1-5).
+struct RtSphereAos {
+    float cx, cy, cz, radius;
+    float r, g, b, pad;
+};
+
+// Spheres are tested 32 at a time (one bit per sphere in a 32-bit lane mask), and
+// candidate masks of up to RT_SG_CHUNKS chunks are parked in LDS before the
+// per-lane candidate walk.
+constexpr int RT_CHUNK = 32;
+constexpr int RT_SG_CHUNKS = 16;
+// Largest sphere count whose geometry stream is staged in LDS (16 B per sphere).
+constexpr int RT_MAX_LDS_SPHERES = 4096;
+// Pixels a wave takes from the shared work counter at a time.
+constexpr unsigned RT_SPAN = 256;
+
+struct RtParams {
+    // camera (reference UBO, includes/scene.hpp:22-29)
+    float fwd[3], right[3], up[3], pos[3];
+    int sphere_count;  // loop bound of Trace(): ubo.sphereCount
+    int n_pad;         // sphere_count rounded up to a multiple of RT_CHUNK
+    int width, height;
+    int tile_col0;     // first column of 8x8 tiles rendered
+    int tile_cols;     // number of tile columns rendered
+    int tile_row0;     // first row of 8x8 tiles rendered
+    int tile_rows;     // number of tile rows rendered
+    unsigned total_pixels;  // tile_cols * tile_rows * 64
+    int max_depth;
+    unsigned frame0;   // ubo.frameCount
+    int n_frames;
+    int frame_stride;
+    int clear_mode;    // RT_CLEAR_*
+    // crop traced in record mode
+    int rec_x0, rec_y0, rec_w, rec_h;
+
+    const RtSphereAos* spheres;  // AoS copy, read for centre/albedo of the winning sphere
+    const float4* geom;          // pair-packed geometry stream of the active float profile
+    float4* accum;               // width*height rgba32f
+    uint32_t* color;             // width*height rgba8
+    unsigned* work_counter;      // zeroed before every stream-kernel launch
+    unsigned long long* rays;    // += Trace() calls
+    rt_record* records;          // record mode only
+    float* rec_light;            // record mode only (may be null)
+};

@@ -1,0 +1,337 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (raytracing_amd.Renderer ->
+libraytracing_amd.so), against the CPU oracle on the same inputs.
+
+Bar: bit-exact.  RNG hashes, per-bounce hit indices, per-frame light, the float4 accumulation
+image, the rgba8 colour image and the ray count must all be identical to the oracle's, for
+both float profiles and both kernels.  (The oracle itself is "parity unpinned" against the
+reference for floating point -- see oracle/rt_oracle.h -- so this proves kernel == oracle.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+PROFILES = [("strict", 0), ("fused", 1)]
+KERNELS = [("stream", 0), ("tile", 1)]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracing_amd
+
+    return raytracing_amd
+
+
+def _render_gpu(rt, scene, w, h, *, profile, kernel, n_frames, frame0=1, depth=50, stride=1,
+                clear=0, rows=None, launch=None, split_dispatch=False, sphere_count=None):
+    with rt.Renderer(w, h) as r:
+        r.set_profile(profile)
+        r.set_kernel(kernel)
+        r.set_max_depth(depth)
+        r.set_frame_schedule(stride, clear)
+        if rows:
+            r.set_tile_rows(*rows)
+        if launch:
+            r.set_launch(*launch)
+        r.upload_spheres(scene.spheres)
+        ubo = scene.camera.copy()
+        if sphere_count is not None:
+            ubo["sphereCount"][0] = sphere_count
+        if split_dispatch:
+            for j in range(n_frames):
+                ubo["frameCount"][0] = frame0 + j * stride
+                r.set_uniforms(ubo)
+                r.dispatch(1)
+        else:
+            ubo["frameCount"][0] = frame0
+            r.set_uniforms(ubo)
+            r.dispatch(n_frames)
+        return r.read_accum(), r.read_color(), r.counters()
+
+
+def _render_cpu(scene, w, h, *, profile, n_frames, frame0=1, depth=50, stride=1, clear=0, rows=None,
+                sphere_count=None):
+    ubo = scene.camera.copy()
+    ubo["frameCount"][0] = frame0
+    if sphere_count is not None:
+        ubo["sphereCount"][0] = sphere_count
+    return O.render(ubo, scene.spheres, w, h, max_depth=depth, profile=profile, n_frames=n_frames,
+                    frame_stride=stride, clear_mode=clear, rows=rows, threads=8)
+
+
+# ---------------------------------------------------------------- device float semantics
+
+def test_device_arithmetic_is_ieee(rt):
+    """sqrt, divide, fma, two-rounding mul-add, uint->float and unorm8 on the device match the
+    host bit for bit, including subnormals: the premise of every bit-exact claim below."""
+    rng = np.random.default_rng(1)
+    n = 1 << 16
+    a = np.concatenate([rng.uniform(0, 1e6, n // 2), 10.0 ** rng.uniform(-44, 38, n // 2)]).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.uniform(-20, 20, n)).astype(np.float32)
+    c = (rng.standard_normal(n) * 10.0 ** rng.uniform(-10, 10, n)).astype(np.float32)
+    b[b == 0] = 1.0
+    with rt.Renderer(8, 8) as r, np.errstate(all="ignore"):
+        assert np.array_equal(_bits(r.debug_math(0, a)), _bits(np.sqrt(a)))
+        assert np.array_equal(_bits(r.debug_math(1, a, b)), _bits(a / b))
+        fma = (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64))
+        # float64 holds a*b exactly; the sum can round twice only on exact ties, which the
+        # comparison below tolerates by also accepting the neighbouring float
+        got = r.debug_math(2, a, b, c)
+        want = fma.astype(np.float32)
+        near = np.nextafter(want, got)
+        assert np.all((_bits(got) == _bits(want)) | (_bits(got) == _bits(near)) | np.isnan(want))
+        assert np.mean(_bits(got) == _bits(want)) > 0.999
+        two = (a * b + c).astype(np.float32)
+        assert np.array_equal(_bits(r.debug_math(3, a, b, c)), _bits(two))
+        h = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        h[:4] = [0, 0xFFFFFFFF, 0x80000000, 0xFFFFFF80]
+        want = (h.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
+        assert np.array_equal(_bits(r.debug_math(4, h.view(np.float32))), _bits(want))
+        pos = a[a > 0]
+        assert np.array_equal(_bits(r.debug_math(5, pos)), _bits(np.float32(1.0) / np.sqrt(pos)))
+        v = rng.uniform(-0.5, 1.5, n).astype(np.float32)
+        want8 = np.array([O.lib().rto_unorm8(float(x)) for x in v[:4096]], np.uint32)
+        assert np.array_equal(_bits(r.debug_math(6, v[:4096])), want8)
+        wanth = np.array([O.wang_hash(int(x)) for x in h[:4096]], np.uint32)
+        assert np.array_equal(_bits(r.debug_math(7, h[:4096].view(np.float32))), wanth)
+
+
+# ---------------------------------------------------------------- records: hashes + hit indices
+
+@pytest.mark.parametrize("kname,kernel", KERNELS)
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_records_match_golden_and_oracle(rt, default_scene, pname, profile, kname, kernel):
+    gold = np.load(os.path.join(GOLDEN, "default_crop16.npz"))
+    with rt.Renderer(1280, 720) as r:
+        r.set_profile(profile)
+        r.set_kernel(kernel)
+        r.upload_spheres(default_scene.spheres)
+        for frame in (1, 2, 64):
+            ubo = default_scene.camera.copy()
+            ubo["frameCount"][0] = frame
+            r.set_uniforms(ubo)
+            rec, light = r.trace_crop(1, 604, 197, 16, 16)
+            assert np.array_equal(rec["hit"][0], gold[f"{pname}_hit_f{frame}"].astype(np.int32))
+            assert np.array_equal(rec["hash"][0], gold[f"{pname}_hash_f{frame}"])
+            assert np.array_equal(_bits(light[0]), _bits(gold[f"{pname}_light_f{frame}"]))
+
+
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_records_multi_frame_rtiow(rt, rtiow_scene, pname, profile):
+    """484 spheres (16 chunks, last one ragged), 3 strided frames, unaligned crop."""
+    w, h = 640, 360
+    with rt.Renderer(w, h) as r:
+        r.set_profile(profile)
+        r.set_max_depth(12)
+        r.set_frame_schedule(3, 0)
+        r.upload_spheres(rtiow_scene.spheres)
+        ubo = rtiow_scene.camera.copy()
+        ubo["frameCount"][0] = 5
+        r.set_uniforms(ubo)
+        rec, light = r.trace_crop(3, 301, 99, 21, 13)
+    crec, clight = O.trace_crop(ubo, rtiow_scene.spheres, w, h, 301, 99, 21, 13, max_depth=12, profile=profile,
+                                n_frames=3, frame_stride=3)
+    assert np.array_equal(rec["hit"], crec["hit"])
+    assert np.array_equal(rec["hash"], crec["hash"])
+    assert np.array_equal(_bits(light), _bits(clight))
+    assert (crec["hit"] >= 0).sum(axis=-1).max() >= 4
+
+
+# ---------------------------------------------------------------- images
+
+@pytest.mark.parametrize("kname,kernel", KERNELS)
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_image_matches_golden(rt, default_scene, pname, profile, kname, kernel):
+    gold = np.load(os.path.join(GOLDEN, "default_64x36.npz"))
+    acc, col, cnt = _render_gpu(rt, default_scene, 64, 36, profile=profile, kernel=kernel, n_frames=64)
+    assert np.array_equal(_bits(acc), _bits(gold[f"{pname}_accum_f64"]))
+    assert np.array_equal(col, gold[f"{pname}_color_f64"])
+    assert cnt["rays"] == int(gold[f"{pname}_rays"][1])
+    assert cnt["paths"] == 64 * 32 * 64
+    assert not acc[32:].any()  # remainder rows are never rendered
+
+
+@pytest.mark.parametrize("kname,kernel", KERNELS)
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_default_scene_720p_depth8(rt, default_scene, pname, profile, kname, kernel):
+    """Config 'default': 1280x720, depth 8 -- a few frames against the oracle, whole image."""
+    acc, col, cnt = _render_gpu(rt, default_scene, 1280, 720, profile=profile, kernel=kernel, n_frames=3, depth=8)
+    cacc, ccol, crays = _render_cpu(default_scene, 1280, 720, profile=profile, n_frames=3, depth=8)
+    assert np.array_equal(_bits(acc), _bits(cacc))
+    assert np.array_equal(col, ccol)
+    assert cnt["rays"] == crays
+
+
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_rtiow_image(rt, rtiow_scene, pname, profile):
+    acc, col, cnt = _render_gpu(rt, rtiow_scene, 320, 184, profile=profile, kernel=0, n_frames=4)
+    cacc, ccol, crays = _render_cpu(rtiow_scene, 320, 184, profile=profile, n_frames=4)
+    assert np.array_equal(_bits(acc), _bits(cacc))
+    assert np.array_equal(col, ccol)
+    assert cnt["rays"] == crays
+
+
+@pytest.mark.parametrize("count", [0, 1, 2, 31, 32, 33, 63, 64, 65, 513, 1025])
+def test_sphere_counts_ragged_chunks(rt, count):
+    """Empty scene, single sphere, chunk boundaries (32), supergroup boundaries (512, 1024)."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, max(count, 3), 11)
+    for profile in (0, 1):
+        acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=profile, kernel=0, n_frames=2, depth=6,
+                                    sphere_count=count)
+        cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=profile, n_frames=2, depth=6, sphere_count=count)
+        assert np.array_equal(_bits(acc), _bits(cacc)), (count, profile)
+        assert np.array_equal(col, ccol)
+        assert cnt["rays"] == crays
+
+
+def test_stress_4096_spheres_crop(rt):
+    """Config 'stress4096' (depth 50): records on a crop vs the oracle, both kernels agree on an image."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, 4096, 3)
+    w, h = 256, 144
+    ubo = scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    with rt.Renderer(w, h) as r:
+        r.upload_spheres(scene.spheres)
+        r.set_uniforms(ubo)
+        rec, light = r.trace_crop(1, 120, 64, 16, 8)
+        crec, clight = O.trace_crop(ubo, scene.spheres, w, h, 120, 64, 16, 8)
+        assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(rec["hash"], crec["hash"])
+        assert np.array_equal(_bits(light), _bits(clight))
+        r.dispatch(1)
+        a_stream = r.read_accum()
+        r.set_kernel(1)
+        r.dispatch(1)
+        a_tile = r.read_accum()
+    assert np.array_equal(_bits(a_stream), _bits(a_tile))
+    cacc, _, _ = O.render(ubo, scene.spheres, w, h, threads=8)
+    assert np.array_equal(_bits(a_stream), _bits(cacc))
+
+
+# ---------------------------------------------------------------- dispatch semantics
+
+def test_batched_frames_equal_single_dispatches(rt, default_scene):
+    a1, c1, n1 = _render_gpu(rt, default_scene, 256, 144, profile=0, kernel=0, n_frames=9)
+    a2, c2, n2 = _render_gpu(rt, default_scene, 256, 144, profile=0, kernel=0, n_frames=9, split_dispatch=True)
+    assert np.array_equal(_bits(a1), _bits(a2)) and np.array_equal(c1, c2) and n1["rays"] == n2["rays"]
+
+
+def test_accumulation_continues_without_clear(rt, default_scene):
+    """Frames 1..4 then 5..8 in two dispatches == frames 1..8 in one; frame 1 clears junk."""
+    with rt.Renderer(128, 72) as r:
+        r.upload_spheres(default_scene.spheres)
+        r.write_accum(np.full((72, 128, 4), 3.0, np.float32))
+        ubo = default_scene.camera.copy()
+        ubo["frameCount"][0] = 1
+        r.set_uniforms(ubo)
+        r.dispatch(4)
+        ubo["frameCount"][0] = 5
+        r.set_uniforms(ubo)
+        r.dispatch(4)
+        acc, col = r.read_accum(), r.read_color()
+    ubo["frameCount"][0] = 1
+    cacc, ccol, _ = O.render(ubo, default_scene.spheres, 128, 72, n_frames=8,
+                             accum=np.full((72, 128, 4), 3.0, np.float32))
+    assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol)
+
+
+def test_tile_rows_and_frame_stride_split(rt, default_scene):
+    """The two multi-GPU partitions, on one GPU: bands of tile rows, and frames by stride."""
+    w, h = 192, 112  # 14 tile rows
+    full, fcol, fn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=4)
+    top, _, tn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=4, rows=(0, 5))
+    bot, _, bn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=4, rows=(5, 14))
+    assert not top[40:].any() and not bot[:40].any()
+    assert np.array_equal(_bits(top + bot), _bits(full)) and tn["rays"] + bn["rays"] == fn["rays"]
+    # frames {1,3} + frames {2,4}: same samples; only the float summation order differs
+    a, _, an = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=2, frame0=1, stride=2, clear=1)
+    b, _, bn2 = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=2, frame0=2, stride=2, clear=1)
+    ca, _, _ = _render_cpu(default_scene, w, h, profile=0, n_frames=2, frame0=1, stride=2, clear=1)
+    cb, _, _ = _render_cpu(default_scene, w, h, profile=0, n_frames=2, frame0=2, stride=2, clear=1)
+    assert np.array_equal(_bits(a), _bits(ca)) and np.array_equal(_bits(b), _bits(cb))
+    assert an["rays"] + bn2["rays"] == fn["rays"]
+    np.testing.assert_allclose(a + b, full, rtol=1e-6, atol=1e-6)
+
+
+def test_launch_geometry_does_not_change_bits(rt, rtiow_scene):
+    ref = None
+    for launch in [(0, 0), (1, 64), (7, 128), (300, 256), (64, 1024), (2048, 64)]:
+        acc, col, cnt = _render_gpu(rt, rtiow_scene, 160, 96, profile=1, kernel=0, n_frames=2, depth=10, launch=launch)
+        if ref is None:
+            ref = (acc, col, cnt["rays"])
+        assert np.array_equal(_bits(acc), _bits(ref[0])) and np.array_equal(col, ref[1]) and cnt["rays"] == ref[2], launch
+
+
+def test_resolve_and_resize(rt, default_scene):
+    with rt.Renderer(64, 40) as r:
+        r.upload_spheres(default_scene.spheres)
+        ubo = default_scene.camera.copy()
+        ubo["frameCount"][0] = 1
+        r.set_uniforms(ubo)
+        r.dispatch(3)
+        acc = r.read_accum()
+        r.resolve(4.0)
+        col = r.read_color()
+        want = np.floor(np.clip(acc[..., :3] / np.float32(4.0), 0, 1) * np.float32(255.0) + np.float32(0.5))
+        assert np.array_equal(col[..., :3], want.astype(np.uint8))
+        r.resize(128, 72)
+        r.dispatch(1)
+        acc2 = r.read_accum()
+    cacc, _, _ = O.render(ubo, default_scene.spheres, 128, 72)
+    assert np.array_equal(_bits(acc2), _bits(cacc))
+
+
+def test_errors_are_reported(rt, default_scene):
+    with rt.Renderer(64, 40) as r:
+        with pytest.raises(rt.RtError):
+            r.dispatch(1)  # no uniforms yet
+        r.upload_spheres(default_scene.spheres[:10])
+        r.set_uniforms(default_scene.camera)  # sphereCount 40 > 10 uploaded
+        with pytest.raises(rt.RtError):
+            r.dispatch(1)
+        with pytest.raises(rt.RtError):
+            r.set_max_depth(0)
+        with pytest.raises(rt.RtError):
+            r.set_launch(0, 100)
+    with pytest.raises(rt.RtError):
+        rt.Renderer(0, 10)
+
+
+# ---------------------------------------------------------------- full-size properties
+
+def test_full_size_4k_stream_equals_tile(rt, rtiow_scene):
+    """BASELINE size (3840x2160, ~500 spheres): too big for the oracle in seconds, so check the
+    two independently written kernels against each other over the whole image, the ray
+    counter, and the oracle on a strided sample of tiles."""
+    w, h = 3840, 2160
+    with rt.Renderer(w, h) as r:
+        r.set_profile(1)
+        r.upload_spheres(rtiow_scene.spheres)
+        ubo = rtiow_scene.camera.copy()
+        ubo["frameCount"][0] = 1
+        r.set_uniforms(ubo)
+        r.dispatch(2)
+        a_stream, c_stream, n_stream = r.read_accum(), r.read_color(), r.counters()["rays"]
+        r.reset_counters()
+        r.set_kernel(1)
+        r.dispatch(2)
+        a_tile, c_tile, n_tile = r.read_accum(), r.read_color(), r.counters()["rays"]
+        assert np.array_equal(_bits(a_stream), _bits(a_tile))
+        assert np.array_equal(c_stream, c_tile)
+        assert n_stream == n_tile
+        assert np.all(a_stream[:2160 // 8 * 8, :, 3] == 2.0)
+        for (x0, y0) in [(0, 0), (1912, 1080), (3832, 2152), (777, 1501)]:
+            rec, light = r.trace_crop(2, x0, y0, 8, 8)
+            crec, clight = O.trace_crop(ubo, rtiow_scene.spheres, w, h, x0, y0, 8, 8, profile=1, n_frames=2)
+            assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(rec["hash"], crec["hash"])
+            assert np.array_equal(_bits(light), _bits(clight))
+            # the image holds exactly the sum of the recorded lights, in frame order
+            assert np.array_equal(_bits(a_stream[y0:y0 + 8, x0:x0 + 8, :3]), _bits(clight[1] + (clight[0] + np.float32(0.0))))
