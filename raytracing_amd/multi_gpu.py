@@ -1,0 +1,99 @@
+"""Partitioning the render across GPUs (one process per GPU, torch.distributed).
+
+The reference is single-GPU.  Pixels and frames are independent, so the path shards two ways,
+each with one exchange step:
+
+SampleSplit  rank g of G renders frame numbers g+1, g+1+G, ... (the RNG formula is untouched,
+             so the union of samples is exactly the single-GPU sample set), accumulates locally,
+             and one sum-reduce of the float4 accumulation image to rank 0 ends the job.  Only
+             the float summation order differs from a single-GPU run.
+TileSplit    rank g renders a band of 8x8-tile rows every frame (interactive mode) and sends its
+             band of the rgba8 image to rank 0; bit-identical to a single-GPU frame.
+
+Both classes only compute schedules and move tensors; the rendering is done by whatever
+`renderer` object they are handed (raytracing_amd.Renderer on a GPU).
+"""
+from __future__ import annotations
+
+from .renderer import CLEAR_FIRST, CLEAR_NEVER
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+class SampleSplit:
+    def __init__(self, rank: int, world: int):
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.rank, self.world = rank, world
+
+    def schedule(self, step: int, frames_per_step: int, restart: bool = False):
+        """(first frameCount, frame stride, number of frames, clear mode) of this rank at `step`.
+
+        Step s covers the global frames s*F*G+1 .. (s+1)*F*G; rank g takes every G-th of them
+        starting at g+1.  The accumulation is zeroed at step 0 (frame 1 is where the reference
+        clears, res/shaders/shader.comp:79-81; every rank has to clear its own copy)."""
+        first = step * frames_per_step * self.world + self.rank + 1
+        clear = CLEAR_FIRST if (step == 0 or restart) else CLEAR_NEVER
+        return first, self.world, frames_per_step, clear
+
+    def dispatch(self, renderer, scene, step: int, frames_per_step: int, restart: bool = False) -> None:
+        first, stride, n, clear = self.schedule(step, frames_per_step, restart)
+        renderer.set_frame_schedule(stride, clear)
+        ubo = scene.camera.copy()
+        ubo["frameCount"][0] = first
+        renderer.set_uniforms(ubo)
+        renderer.dispatch(n)
+
+    def reduce(self, accum, dst: int = 0) -> None:
+        """Sum the per-rank accumulation images into rank `dst` (RCCL on GPUs, gloo on CPU)."""
+        if self.world > 1:
+            _dist().reduce(accum, dst=dst, op=_dist().ReduceOp.SUM)
+
+    def divisor(self, steps: int, frames_per_step: int) -> float:
+        """The shader divides by frameCount + 1 (shader.comp:129); frameCount of the last frame
+        of the whole job is the total number of frames."""
+        return float(steps * frames_per_step * self.world + 1)
+
+
+class TileSplit:
+    def __init__(self, rank: int, world: int, height: int):
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.rank, self.world = rank, world
+        self.tile_rows = height // 8  # the reference dispatches floor(H/8) rows of groups
+        base, extra = divmod(self.tile_rows, world)
+        starts = [g * base + min(g, extra) for g in range(world + 1)]
+        self.bands = [(starts[g], starts[g + 1]) for g in range(world)]
+
+    @property
+    def rows(self):
+        return self.bands[self.rank]
+
+    def apply(self, renderer) -> None:
+        r0, r1 = self.rows
+        if r1 <= r0:
+            # a rank with no rows renders nothing: an empty band is expressed as [rows, rows)
+            renderer.set_tile_rows(self.tile_rows, self.tile_rows)
+        else:
+            renderer.set_tile_rows(r0, r1)
+
+    def gather(self, image, dst: int = 0) -> None:
+        """Move every rank's band of `image` (H x W [x C], rows = pixels) into rank `dst`'s copy."""
+        if self.world == 1:
+            return
+        dist = _dist()
+        if self.rank == dst:
+            reqs = []
+            for g, (r0, r1) in enumerate(self.bands):
+                if g != dst and r1 > r0:
+                    reqs.append(dist.irecv(image[r0 * 8:r1 * 8], src=g))
+            for q in reqs:
+                q.wait()
+        else:
+            r0, r1 = self.rows
+            if r1 > r0:
+                dist.send(image[r0 * 8:r1 * 8].contiguous(), dst=dst)
