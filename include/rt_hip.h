@@ -47,8 +47,11 @@ enum {
 
 /* Which kernel runs a dispatch.  All give bit-identical images. */
 enum {
-    RT_KERNEL_STREAM = 0, /* persistent waves; a lane whose path ends takes the next pixel   */
-    RT_KERNEL_TILE = 1    /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
+    RT_KERNEL_STREAM = 0, /* persistent waves; a lane whose path ends takes the next pixel;
+                             picks one of the two geometry sources below by sphere count      */
+    RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
+    RT_KERNEL_STREAM_SGPR = 2, /* STREAM, sieve geometry read through the scalar cache (SGPRs) */
+    RT_KERNEL_STREAM_LDS = 3   /* STREAM, sieve geometry read from the LDS copy                */
 };
 
 /* When the accumulation texel is zeroed. */
@@ -167,6 +170,14 @@ int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* t
    No reference counterpart. */
 int rt_debug_math(rt_context* ctx, int op, const float* a, const float* b, const float* c,
                   float* out, int n);
+
+/* Test hook: runs the stream kernel's conservative sieve on n_rays caller-supplied rays
+   (6 floats each: origin xyz, direction xyz) against the uploaded spheres and compares
+   it with the shader's literal discriminant.  out[0], out[1]: spheres the sieve rejected
+   although the discriminant under the STRICT / FUSED profile was not negative (must be
+   0); out[2]: spheres with a non-negative STRICT discriminant; out[3]: spheres the sieve
+   passed.  No reference counterpart. */
+int rt_debug_sieve_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[4]);
 
 const char* rt_last_error(void);
 

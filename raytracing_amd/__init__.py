@@ -6,7 +6,7 @@ the benchmark.
 """
 from .scene import Scene, SPHERE_DTYPE, UBO_DTYPE, DEFAULT_SCENE, KIND_RTIOW, KIND_CUBE  # noqa: F401
 from .renderer import (  # noqa: F401
-    Renderer, RECORD_DTYPE, PROFILE_STRICT, PROFILE_FUSED, KERNEL_STREAM, KERNEL_TILE,
+    Renderer, RECORD_DTYPE, PROFILE_STRICT, PROFILE_FUSED, KERNEL_STREAM, KERNEL_TILE, KERNEL_STREAM_SGPR, KERNEL_STREAM_LDS,
     CLEAR_REFERENCE, CLEAR_FIRST, CLEAR_NEVER,
 )
 from ._native import RtError  # noqa: F401

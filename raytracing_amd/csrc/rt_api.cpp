@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -15,11 +16,13 @@
 
 // launchers defined in rt_kernels.hip
 size_t rt_stream_lds_bytes(int n_pad, int threads);
-hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int blocks, int threads,
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, bool sgeom, int blocks, int threads,
                             hipStream_t st);
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
 hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
                              int y1, float divisor, hipStream_t st);
+hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
+                                 hipStream_t st);
 hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const float* c, float* out,
                                 int n, hipStream_t st);
 
@@ -63,7 +66,8 @@ struct rt_context {
     uint32_t* color = nullptr;
 
     RtSphereAos* d_spheres = nullptr;  // AoS copy
-    float4* d_geom[2] = {nullptr, nullptr};  // pair-packed geometry per float profile
+    float4* d_geom = nullptr;  // pair-packed sieve geometry
+    float* d_radius = nullptr; // radii, padded
     int n_spheres = 0;   // spheres in the buffer (Scene::spheres().size())
     int sphere_cap = 0;  // allocated entries (multiple of RT_CHUNK)
 
@@ -160,7 +164,8 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     P.frame_stride = c->frame_stride;
     P.clear_mode = c->clear_mode;
     P.spheres = c->d_spheres;
-    P.geom = c->d_geom[c->profile == RT_PROFILE_FUSED ? 1 : 0];
+    P.geom = c->d_geom;
+    P.radius = c->d_radius;
     P.accum = c->accum;
     P.color = c->color;
     P.work_counter = c->d_work;
@@ -199,7 +204,10 @@ int launch(rt_context* c, const RtParams& P, bool record)
     if (rt_stream_lds_bytes(P.n_pad, threads) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     HIP_TRY(hipMemsetAsync(c->d_work, 0, 256, c->stream));
-    HIP_TRY(rt_launch_stream(P, fused, record, blocks, threads, c->stream));
+    // The scalar cache serves the sieve faster than LDS while the geometry stream fits in it.
+    const bool sgeom = c->kernel == RT_KERNEL_STREAM_SGPR ||
+                       (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES);
+    HIP_TRY(rt_launch_stream(P, fused, record, sgeom, blocks, threads, c->stream));
     return RT_OK;
 }
 
@@ -256,8 +264,8 @@ int rt_destroy(rt_context* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)free_images(c);
     if (c->d_spheres) (void)hipFree(c->d_spheres);
-    if (c->d_geom[0]) (void)hipFree(c->d_geom[0]);
-    if (c->d_geom[1]) (void)hipFree(c->d_geom[1]);
+    if (c->d_geom) (void)hipFree(c->d_geom);
+    if (c->d_radius) (void)hipFree(c->d_radius);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -287,40 +295,42 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     HIP_TRY(hipStreamSynchronize(c->stream));  // no launch may still read the old buffers
     if (cap > c->sphere_cap) {
         if (c->d_spheres) HIP_TRY(hipFree(c->d_spheres));
-        if (c->d_geom[0]) HIP_TRY(hipFree(c->d_geom[0]));
-        if (c->d_geom[1]) HIP_TRY(hipFree(c->d_geom[1]));
+        if (c->d_geom) HIP_TRY(hipFree(c->d_geom));
+        if (c->d_radius) HIP_TRY(hipFree(c->d_radius));
         c->d_spheres = nullptr;
-        c->d_geom[0] = c->d_geom[1] = nullptr;
+        c->d_geom = nullptr;
+        c->d_radius = nullptr;
         c->sphere_cap = 0;
         HIP_TRY(hipMalloc(&c->d_spheres, (size_t)cap * sizeof(RtSphereAos)));
-        HIP_TRY(hipMalloc(&c->d_geom[0], (size_t)cap * sizeof(float4)));
-        HIP_TRY(hipMalloc(&c->d_geom[1], (size_t)cap * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_geom, (size_t)cap * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_radius, (size_t)cap * sizeof(float)));
         c->sphere_cap = cap;
     }
-    // AoS copy (zero padded) + the two pair-packed geometry streams: for the pair (2k, 2k+1)
-    //   float4 {cx0, cx1, cy0, cy1}, float4 {cz0, cz1, w0, w1},
-    // w = -(r*r) for the STRICT profile and r for the FUSED one (dot(oc,oc) - r*r is
-    // dd + w resp. fma(-w, w, dd)).
+    // AoS copy (zero padded), the radii, and the pair-packed sieve geometry: for the pair
+    // (2k, 2k+1)   float4 {cx0, cx1, cy0, cy1}, float4 {cz0, cz1, w0, w1},
+    // w = r*r - c.c + margin*(c.c + r*r), evaluated in double and rounded UP to float so the
+    // margin is never eroded (see sieve_chunk in rt_kernels.hip).
     std::vector<RtSphereAos> host(cap);
     memset(host.data(), 0, host.size() * sizeof(RtSphereAos));
     if (count) memcpy(host.data(), aos, (size_t)count * sizeof(RtSphereAos));
-    std::vector<float> g0((size_t)cap * 4), g1((size_t)cap * 4);
+    std::vector<float> geom((size_t)cap * 4), radius((size_t)cap);
     for (int i = 0; i < cap; i++) {
         const RtSphereAos& s = host[i];
         const size_t base = (size_t)(i >> 1) * 8 + (i & 1);
-        const float rr = s.radius * s.radius;
-        float* gs[2] = {g0.data(), g1.data()};
-        for (int m = 0; m < 2; m++) {
-            gs[m][base + 0] = s.cx;
-            gs[m][base + 2] = s.cy;
-            gs[m][base + 4] = s.cz;
-        }
-        g0[base + 6] = -rr;
-        g1[base + 6] = s.radius;
+        const double cc = (double)s.cx * s.cx + (double)s.cy * s.cy + (double)s.cz * s.cz;
+        const double rr = (double)s.radius * s.radius;
+        const double w = rr - cc + (double)RT_SIEVE_MARGIN * (cc + rr);
+        float wf = (float)w;
+        if ((double)wf < w) wf = std::nextafter(wf, INFINITY);
+        geom[base + 0] = s.cx;
+        geom[base + 2] = s.cy;
+        geom[base + 4] = s.cz;
+        geom[base + 6] = wf;
+        radius[i] = s.radius;
     }
     HIP_TRY(hipMemcpy(c->d_spheres, host.data(), (size_t)cap * sizeof(RtSphereAos), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_geom[0], g0.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_geom[1], g1.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_geom, geom.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_radius, radius.data(), (size_t)cap * sizeof(float), hipMemcpyHostToDevice));
     c->n_spheres = count;
     return RT_OK;
 }
@@ -353,7 +363,7 @@ int rt_set_profile(rt_context* c, int profile)
 int rt_set_kernel(rt_context* c, int kernel)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    if (kernel != RT_KERNEL_STREAM && kernel != RT_KERNEL_TILE)
+    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_STREAM_LDS)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
@@ -595,6 +605,35 @@ int rt_debug_math(rt_context* c, int op, const float* a, const float* b, const f
     if (e == hipSuccess) e = hipMemcpy(out, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RT_E_HIP, "math probe: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+// Sieve audit for the parity tests: runs the stream kernel's sieve on n_rays caller-supplied rays
+// (6 floats each: origin, direction) against the uploaded spheres.  out[0], out[1]: spheres
+// rejected by the sieve whose literal discriminant (STRICT, FUSED) is not negative -- must be 0;
+// out[2]: spheres with a non-negative STRICT discriminant; out[3]: spheres the sieve passed.
+int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t out[4])
+{
+    if (!c || !rays || !out || n_rays <= 0) return fail(RT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    RtParams P;
+    int rc = make_params(c, 1, &P);
+    if (rc != RT_OK) return rc;
+    if (P.n_pad > RT_MAX_LDS_SPHERES) return fail(RT_E_INVALID, "too many spheres for the sieve audit");
+    float* d_rays = nullptr;
+    unsigned long long* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 6 * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_out, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt_launch_sieve_audit(P, d_rays, n_rays, d_out, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    unsigned long long host[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(host, d_out, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RT_E_HIP, "sieve audit: %s", hipGetErrorString(e));
+    for (int i = 0; i < 4; i++) out[i] = host[i];
     return RT_OK;
 }
 

@@ -29,6 +29,7 @@
 #include "rt_params.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define RT_FLT_MAX 3.402823466e+38f  // def.glsl:27
 
@@ -187,21 +188,17 @@ __device__ __forceinline__ bool path_bounce(Path& p, const RtParams& P, int idx,
     return p.bounce >= P.max_depth;
 }
 
-// shader.comp:44-60 for one sphere, literally.  w is the radius (FUSED) or -(r*r) (STRICT).
+// shader.comp:44-60 for one sphere, literally.  The square root and the divide are skipped when
+// b >= 0: then -b - sqrt(disc) <= 0, so t > 0 is false whatever the root is -- same outcome.
 template <bool FUSED>
 __device__ __forceinline__ void test_sphere(const Path& p, float a, float cx, float cy, float cz,
-                                            float w, int i, float& best, int& idx)
+                                            float r, int i, float& best, int& idx)
 {
     const float ocx = p.ox - cx, ocy = p.oy - cy, ocz = p.oz - cz;
     const float b = 2.0f * dot3<FUSED>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
-    const float dd = dot3<FUSED>(ocx, ocy, ocz, ocx, ocy, ocz);
-    float c;
-    if constexpr (FUSED)
-        c = __builtin_fmaf(-w, w, dd);  // dot(oc,oc) - r*r
-    else
-        c = dd + w;
+    const float c = mad<FUSED>(-r, r, dot3<FUSED>(ocx, ocy, ocz, ocx, ocy, ocz));  // dot(oc,oc) - r*r
     const float disc = mad<FUSED>(b, b, -((4.0f * a) * c));
-    if (!(disc < 0.0f)) {
+    if (!(disc < 0.0f) && b < 0.0f) {
         const float t = (-b - sqrtf(disc)) / (2.0f * a);
         if (t > 0.0f && t < best) {
             best = t;
@@ -283,9 +280,7 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
             int idx = -1;
             for (int i = 0; i < P.sphere_count; i++) {
                 const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
-                float w;
-                if constexpr (FUSED) w = g.w; else w = -(g.w * g.w);
-                test_sphere<FUSED>(p, a, g.x, g.y, g.z, w, i, best, idx);
+                test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx);
             }
             if (alive) {
                 nrays++;
@@ -306,48 +301,104 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
 
 // -------------------------------------------------------------- stream kernel
 
-// Sieve of one chunk (32 spheres = 16 pairs).  g points at the chunk's 32 float4s in LDS:
-// pair k is {cx0,cx1,cy0,cy1}, {cz0,cz1,w0,w1}.  Returns a mask whose bit (31-n) is SET when
-// sphere n of the chunk is rejected (q < 0): the sign bit of q is shifted in from the right,
-// sphere 0 first.
-template <bool FUSED>
-__device__ __forceinline__ uint32_t sieve_chunk(const float4* g, v2f ox, v2f oy, v2f oz, v2f dx,
-                                                v2f dy, v2f dz, v2f a)
+// Per-ray constants of the sieve.
+struct SieveRay {
+    v2f nnx, nny, nnz;     // -d / |d|
+    v2f d0;                // (d / |d|) . o
+    v2f p2ox, p2oy, p2oz;  // 2 o
+    v2f no2;               // -(o . o) * (1 - RT_SIEVE_MARGIN)
+};
+
+__device__ __forceinline__ SieveRay sieve_ray(const Path& p, float a)
 {
+    const float inv = __builtin_amdgcn_rsqf(a);  // 1 ulp is plenty: the margin absorbs it
+    const float nx = p.dx * inv, ny = p.dy * inv, nz = p.dz * inv;
+    const float d0 = __builtin_fmaf(nz, p.oz, __builtin_fmaf(ny, p.oy, nx * p.ox));
+    const float o2 = __builtin_fmaf(p.oz, p.oz, __builtin_fmaf(p.oy, p.oy, p.ox * p.ox));
+    const float no2 = o2 * (RT_SIEVE_MARGIN - 1.0f);
+    SieveRay r;
+    r.nnx = v2f{-nx, -nx}; r.nny = v2f{-ny, -ny}; r.nnz = v2f{-nz, -nz};
+    r.d0 = v2f{d0, d0};
+    r.p2ox = v2f{2.0f * p.ox, 2.0f * p.ox};
+    r.p2oy = v2f{2.0f * p.oy, 2.0f * p.oy};
+    r.p2oz = v2f{2.0f * p.oz, 2.0f * p.oz};
+    r.no2 = v2f{no2, no2};
+    return r;
+}
+
+// Sieve of one chunk (32 spheres = 16 pairs).  g points at the chunk's 32 float4s in LDS: pair k
+// is {cx0,cx1,cy0,cy1}, {cz0,cz1,w0,w1} with w = r*r - c.c + margin*(c.c + r*r), rounded up.
+//
+// With n = d/|d| the shader's discriminant is disc = 4|d|^2 (s^2 - C), s = n.(o-c),
+// C = |o-c|^2 - r^2.  The sieve evaluates g = s^2 - C + m in the expanded form
+//     s = n.o - n.c,   -C + m = 2 o.c - o.o(1-margin) + w
+// with fused multiply-adds (8 packed instructions per sphere pair) and rejects a sphere only
+// when g < 0.  m = margin*(o.o + c.c + r*r), margin = 2^-16 = 256 ulp, exceeds the rounding
+// error of this form plus that of the shader's own expression (each below 64 ulp of
+// |d|^2 ((|o|+|c|)^2 + r^2)), so a sphere whose literal discriminant is >= 0 is never
+// rejected; a few near-tangent spheres pass needlessly and are dismissed by the literal test of
+// the walk.  Returns a mask whose bit (31-n) is SET when sphere n of the chunk is rejected: the
+// sign bit of g is shifted in from the right, sphere 0 first.
+__device__ __forceinline__ void sieve_pair(uint32_t& mask, v4f A, v4f B, const SieveRay& r)
+{
+    const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, w = {B.z, B.w};
+    const v2f s = __builtin_elementwise_fma(
+        cz, r.nnz, __builtin_elementwise_fma(cy, r.nny, __builtin_elementwise_fma(cx, r.nnx, r.d0)));
+    const v2f t = __builtin_elementwise_fma(
+        cz, r.p2oz, __builtin_elementwise_fma(cy, r.p2oy, __builtin_elementwise_fma(cx, r.p2ox, r.no2 + w)));
+    const v2f q = __builtin_elementwise_fma(s, s, t);
+    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x), 31);
+    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y), 31);
+}
+
+// The loads of group n+1 (RT_SIEVE_GROUP pairs) are issued before the arithmetic of group n,
+// so their latency is covered by a group's worth of packed math.
+constexpr int RT_SIEVE_GROUP = 4;
+
+template <class GeomPtr>
+__device__ __forceinline__ uint32_t sieve_chunk(GeomPtr g, const SieveRay& r)
+{
+    constexpr int NG = RT_CHUNK / 2 / RT_SIEVE_GROUP;
     uint32_t mask = 0;
+    v4f cur[2 * RT_SIEVE_GROUP], nxt[2 * RT_SIEVE_GROUP];
 #pragma unroll
-    for (int k = 0; k < RT_CHUNK / 2; k++) {
-        const float4 A = g[2 * k], B = g[2 * k + 1];
-        const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, w = {B.z, B.w};
-        const v2f ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-        const v2f s = mad2<FUSED>(ocz, dz, mad2<FUSED>(ocy, dy, ocx * dx));      // dot(oc, d)
-        const v2f dd = mad2<FUSED>(ocz, ocz, mad2<FUSED>(ocy, ocy, ocx * ocx));  // dot(oc, oc)
-        v2f c;
-        if constexpr (FUSED)
-            c = __builtin_elementwise_fma(-w, w, dd);
-        else
-            c = dd + w;
-        // disc = b*b - 4*a*c with b = 2s is exactly 4*(s*s - a*c): scaling by 2 and 4 commutes
-        // with rounding, so q has the sign of the shader's discriminant.
-        const v2f q = mad2<FUSED>(s, s, -(a * c));
-        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x), 31);
-        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y), 31);
+    for (int k = 0; k < 2 * RT_SIEVE_GROUP; k++) cur[k] = g[k];
+#pragma unroll
+    for (int n = 0; n < NG; n++) {
+        if (n + 1 < NG) {
+#pragma unroll
+            for (int k = 0; k < 2 * RT_SIEVE_GROUP; k++) nxt[k] = g[(n + 1) * 2 * RT_SIEVE_GROUP + k];
+        }
+#pragma unroll
+        for (int k = 0; k < RT_SIEVE_GROUP; k++) sieve_pair(mask, cur[2 * k], cur[2 * k + 1], r);
+#pragma unroll
+        for (int k = 0; k < 2 * RT_SIEVE_GROUP; k++) cur[k] = nxt[k];
     }
     return mask;
 }
 
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
-// n_pad*16 B geometry + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B candidate masks.
-template <bool FUSED, bool RECORD>
+// n_pad*16 B sieve geometry + n_pad*4 B radii + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
+//
+// SGEOM selects where the sieve reads the geometry from: false = the LDS copy (wave-uniform
+// ds_read_b128), true = global memory through the scalar cache (s_load into SGPRs, which the
+// packed instructions take directly as their one scalar operand).  The walk reads LDS either way.
+typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
+
+template <bool FUSED, bool RECORD, bool SGEOM>
 __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
 {
     extern __shared__ float4 smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) smem[i] = P.geom[i];
+    float* radius = reinterpret_cast<float*>(smem + P.n_pad);
+    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) {
+        smem[i] = P.geom[i];
+        radius[i] = P.radius[i];
+    }
     __syncthreads();  // the only barrier: waves run independently from here on
-    uint32_t* wmask = reinterpret_cast<uint32_t*>(smem + P.n_pad) + wave * (RT_SG_CHUNKS * 64);
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(radius + P.n_pad) + wave * (RT_SG_CHUNKS * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
@@ -415,15 +466,16 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         float best = RT_FLT_MAX;
         int idx = -1;
         {
-            const v2f ox = {p.ox, p.ox}, oy = {p.oy, p.oy}, oz = {p.oz, p.oz};
-            const v2f dx = {p.dx, p.dx}, dy = {p.dy, p.dy}, dz = {p.dz, p.dz};
-            const v2f a2 = {a, a};
+            const SieveRay sr = sieve_ray(p, a);
             for (int sg = 0; sg < nch; sg += RT_SG_CHUNKS) {
                 const int nsg = min(RT_SG_CHUNKS, nch - sg);
                 uint32_t summary = 0;
                 for (int c = 0; c < nsg; c++) {
-                    const uint32_t rej =
-                        sieve_chunk<FUSED>(smem + (sg + c) * RT_CHUNK, ox, oy, oz, dx, dy, dz, a2);
+                    uint32_t rej;
+                    if constexpr (SGEOM)
+                        rej = sieve_chunk((ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK, sr);
+                    else
+                        rej = sieve_chunk(reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK, sr);
                     // bits of padding spheres beyond sphere_count are never candidates
                     const int nvalid = min(RT_CHUNK, max(0, P.sphere_count - (sg + c) * RT_CHUNK));
                     const uint32_t valid = nvalid >= 32 ? 0xffffffffu : ~(0xffffffffu >> nvalid);
@@ -448,7 +500,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                         cur &= ~(0x80000000u >> b);
                         const int i = curbase + b;
                         const float* f = gf + (i >> 1) * 8 + (i & 1);
-                        test_sphere<FUSED>(p, a, f[0], f[2], f[4], f[6], i, best, idx);
+                        test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx);
                     }
                 }
             }
@@ -474,6 +526,53 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         }
     }
     if constexpr (!RECORD) add_rays(P, nrays);
+}
+
+// ---------------------------------------------------------------- sieve audit
+
+// Test kernel: for caller-supplied rays, runs the sieve exactly as rt_stream_kernel does and
+// compares every bit with the shader's literal discriminant under both float profiles.
+// out[0] / out[1]: spheres the sieve rejected although the STRICT / FUSED discriminant was not
+// negative (must stay 0); out[2]: spheres with a non-negative STRICT discriminant; out[3]: spheres
+// the sieve let through.  One lane per ray; blockDim.x = 256; dynamic LDS = n_pad*16 bytes.
+__global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, const float* rays, int n_rays,
+                                                            unsigned long long* out)
+{
+    extern __shared__ float4 smem[];
+    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) smem[i] = P.geom[i];
+    __syncthreads();
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = ray < n_rays;
+    Path p;
+    p.ox = live ? rays[6 * ray + 0] : 0.f; p.oy = live ? rays[6 * ray + 1] : 0.f; p.oz = live ? rays[6 * ray + 2] : 0.f;
+    p.dx = live ? rays[6 * ray + 3] : 1.f; p.dy = live ? rays[6 * ray + 4] : 0.f; p.dz = live ? rays[6 * ray + 5] : 0.f;
+    unsigned bad_s = 0, bad_f = 0, n_exact = 0, n_sieve = 0;
+    const float a_s = dot3<false>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+    const float a_f = dot3<true>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+    const SieveRay sr = sieve_ray(p, a_s);
+    for (int ch = 0; ch < P.n_pad / RT_CHUNK; ch++) {
+        const uint32_t rej = sieve_chunk(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
+        for (int n = 0; n < RT_CHUNK; n++) {
+            const int i = ch * RT_CHUNK + n;
+            if (i >= P.sphere_count || !live) break;
+            const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
+            const float ocx = p.ox - g.x, ocy = p.oy - g.y, ocz = p.oz - g.z;
+            const float bs = 2.0f * dot3<false>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
+            const float cs = mad<false>(-g.w, g.w, dot3<false>(ocx, ocy, ocz, ocx, ocy, ocz));
+            const float ds = mad<false>(bs, bs, -((4.0f * a_s) * cs));
+            const float bf = 2.0f * dot3<true>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
+            const float cf = mad<true>(-g.w, g.w, dot3<true>(ocx, ocy, ocz, ocx, ocy, ocz));
+            const float df = mad<true>(bf, bf, -((4.0f * a_f) * cf));
+            const bool rejected = (rej >> (31 - n)) & 1u;
+            if (!(ds < 0.0f)) { n_exact++; if (rejected) bad_s++; }
+            if (!(df < 0.0f) && rejected) bad_f++;
+            if (!rejected) n_sieve++;
+        }
+    }
+    if (bad_s) atomicAdd(out + 0, (unsigned long long)bad_s);
+    if (bad_f) atomicAdd(out + 1, (unsigned long long)bad_f);
+    if (n_exact) atomicAdd(out + 2, (unsigned long long)n_exact);
+    if (n_sieve) atomicAdd(out + 3, (unsigned long long)n_sieve);
 }
 
 // ------------------------------------------------------------------- resolve
@@ -515,13 +614,13 @@ __global__ void rt_math_probe_kernel(int op, const float* a, const float* b, con
 
 // ------------------------------------------------------------------ launchers
 
-template <bool FUSED, bool RECORD>
+template <bool FUSED, bool RECORD, bool SGEOM>
 static hipError_t launch_stream(const RtParams& P, int blocks, int threads, size_t lds, hipStream_t st)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD, SGEOM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((rt_stream_kernel<FUSED, RECORD>), dim3(blocks), dim3(threads), lds, st, P);
+    hipLaunchKernelGGL((rt_stream_kernel<FUSED, RECORD, SGEOM>), dim3(blocks), dim3(threads), lds, st, P);
     return hipGetLastError();
 }
 
@@ -534,18 +633,22 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
 
 size_t rt_stream_lds_bytes(int n_pad, int threads)
 {
-    return (size_t)n_pad * sizeof(float4) + (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
+    return (size_t)n_pad * (sizeof(float4) + sizeof(float)) +
+           (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
 }
 
-hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int blocks, int threads,
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, bool sgeom, int blocks, int threads,
                             hipStream_t st)
 {
     const size_t lds = rt_stream_lds_bytes(P.n_pad, threads);
-    if (fused)
-        return record ? launch_stream<true, true>(P, blocks, threads, lds, st)
-                      : launch_stream<true, false>(P, blocks, threads, lds, st);
-    return record ? launch_stream<false, true>(P, blocks, threads, lds, st)
-                  : launch_stream<false, false>(P, blocks, threads, lds, st);
+    if (record)  // the debug twin always takes the LDS path
+        return fused ? launch_stream<true, true, false>(P, blocks, threads, lds, st)
+                     : launch_stream<false, true, false>(P, blocks, threads, lds, st);
+    if (sgeom)
+        return fused ? launch_stream<true, false, true>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, true>(P, blocks, threads, lds, st);
+    return fused ? launch_stream<true, false, false>(P, blocks, threads, lds, st)
+                 : launch_stream<false, false, false>(P, blocks, threads, lds, st);
 }
 
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st)
@@ -568,5 +671,16 @@ hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const fl
                                 int n, hipStream_t st)
 {
     hipLaunchKernelGGL(rt_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, op, a, b, c, out, n);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
+                                 hipStream_t st)
+{
+    const size_t lds = (size_t)P.n_pad * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_sieve_audit_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rt_sieve_audit_kernel, dim3((n_rays + 255) / 256), dim3(256), lds, st, P, rays, n_rays, out);
     return hipGetLastError();
 }

@@ -19,6 +19,10 @@ constexpr int RT_CHUNK = 32;
 constexpr int RT_SG_CHUNKS = 16;
 // Largest sphere count whose geometry stream is staged in LDS (16 B per sphere).
 constexpr int RT_MAX_LDS_SPHERES = 4096;
+// Up to this many spheres RT_KERNEL_STREAM reads the sieve geometry through the scalar cache.
+constexpr int RT_MAX_SGPR_SPHERES = 2048;
+// Relative safety margin of the sieve (2^-16 = 256 ulp): see sieve_chunk in rt_kernels.hip.
+constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
 // Pixels a wave takes from the shared work counter at a time.
 constexpr unsigned RT_SPAN = 256;
 
@@ -42,7 +46,8 @@ struct RtParams {
     int rec_x0, rec_y0, rec_w, rec_h;
 
     const RtSphereAos* spheres;  // AoS copy, read for centre/albedo of the winning sphere
-    const float4* geom;          // pair-packed geometry stream of the active float profile
+    const float4* geom;          // pair-packed sieve geometry: {cx0,cx1,cy0,cy1},{cz0,cz1,w0,w1}
+    const float* radius;         // radii, n_pad entries (read by the literal test of the walk)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
     unsigned* work_counter;      // zeroed before every stream-kernel launch

@@ -18,6 +18,8 @@ PROFILE_STRICT = 0
 PROFILE_FUSED = 1
 KERNEL_STREAM = 0
 KERNEL_TILE = 1
+KERNEL_STREAM_SGPR = 2
+KERNEL_STREAM_LDS = 3
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1
 CLEAR_NEVER = 2
@@ -164,6 +166,13 @@ class Renderer:
         v = [C.c_int() for _ in range(4)]
         N.check(N.lib().rt_get_info(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("device", "cu_count", "blocks", "threads"), (int(x.value) for x in v)))
+
+    def sieve_audit(self, rays: np.ndarray) -> dict:
+        """rays: (n, 6) float32 origin+direction; see rt_debug_sieve_audit in include/rt_hip.h."""
+        arr = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().rt_debug_sieve_audit(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0], out))
+        return {"missed_strict": int(out[0]), "missed_fused": int(out[1]), "exact": int(out[2]), "passed": int(out[3])}
 
     def debug_math(self, op: int, a, b=None, c=None) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)

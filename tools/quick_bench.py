@@ -32,7 +32,7 @@ def main():
         r.upload_spheres(scene.spheres)
         r.set_uniforms(ubo)
         print(r.info())
-        for kname, kernel in (("stream", 0), ("tile", 1)):
+        for kname, kernel in (("lds", 3), ("sgpr", 2), ("tile", 1)):
             for pname, profile in (("strict", 0), ("fused", 1)):
                 r.set_kernel(kernel)
                 r.set_profile(profile)

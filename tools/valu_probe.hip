@@ -24,8 +24,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int NACC = 16;
 
 template <int MODE>
-__global__ void __launch_bounds__(256) probe(float* out, int iters, float c1, float c2)
+__global__ void __launch_bounds__(256) probe(float* out, int iters, float c1, float c2, unsigned long long* cyc)
 {
+    const unsigned long long t0 = clock64();
     __shared__ float4 lds[256];
     lds[threadIdx.x] = make_float4(c1, c2, c1, c2);
     __syncthreads();
@@ -79,29 +80,39 @@ __global__ void __launch_bounds__(256) probe(float* out, int iters, float c1, fl
         t ^= m[k];
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)t;
+    const unsigned long long t1 = clock64();  // s_memtime: shader-clock cycles
+    if ((threadIdx.x & 63) == 0) atomicAdd(cyc, t1 - t0);
 }
 
 template <int MODE>
 static void run(const char* name, int per_iter, float* d_out, int cus)
 {
-    const int iters = 20000;
+    const int iters = 200000;
+    unsigned long long* d_cyc;
+    CHECK(hipMalloc(&d_cyc, 8));
     for (int wps : {1, 2, 4, 8}) {
         const int blocks = cus * wps;  // 256 threads = 4 waves = one per SIMD
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0));
         CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 100, 1.0001f, 0.5f);
+        hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 100, 1.0001f, 0.5f, d_cyc);
         CHECK(hipDeviceSynchronize());
+        CHECK(hipMemset(d_cyc, 0, 8));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0001f, 0.5f);
+        hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0001f, 0.5f, d_cyc);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         const double insts = (double)blocks * 4 * iters * per_iter;  // wave-instructions
         const double per_s = insts / (ms * 1e-3);
-        printf("%-28s waves/SIMD %d  %8.3f ms  %7.2f G wave-inst/s  %6.3f inst/clk/SIMD@2.4GHz\n", name, wps, ms,
-               per_s * 1e-9, per_s / (cus * 4.0) / 2.4e9);
+        unsigned long long cyc = 0;
+        CHECK(hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost));
+        const double wave_cyc = (double)cyc / ((double)blocks * 4);          // mean cycles a wave lived
+        const double clk_ghz = wave_cyc / (ms * 1e-3) * 1e-9;                // shader clock while it ran
+        const double cyc_per_inst_simd = wave_cyc / ((double)iters * per_iter * wps);  // SIMD cycles per wave-inst
+        printf("%-28s waves/SIMD %d  %8.3f ms  %7.2f G wave-inst/s  clock %.2f GHz  %5.2f cyc/inst/SIMD\n", name, wps,
+               ms, per_s * 1e-9, clk_ghz, cyc_per_inst_simd);
         CHECK(hipEventDestroy(e0));
         CHECK(hipEventDestroy(e1));
     }
