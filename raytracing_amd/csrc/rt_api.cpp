@@ -131,6 +131,23 @@ int alloc_images(rt_context* c, int w, int h)
     return RT_OK;
 }
 
+// ceil(2^32 / d), or 0 for d <= 1 (the kernel then skips the division).  With m = ceil(2^32/d),
+// __umulhi(t, m) == t / d whenever t * d < 2^32; launch() checks that for the tile indices.
+unsigned tile_magic(int d)
+{
+    if (d <= 1) return 0u;
+    return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
+}
+
+// Derived fields: call after sphere_count, n_pad and the tile rectangle are set.
+void finish_params(RtParams& P)
+{
+    P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
+    P.tile_cols_magic = tile_magic(P.tile_cols);
+    const int rem = P.sphere_count - (P.n_pad - RT_CHUNK);  // spheres in the last chunk
+    P.last_chunk_valid = (P.n_pad == 0 || rem >= RT_CHUNK) ? 0xffffffffu : ~(0xffffffffu >> rem);
+}
+
 // Fill the launch-independent part of the kernel arguments; validates state.
 int make_params(rt_context* c, int n_frames, RtParams* out)
 {
@@ -157,7 +174,7 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     P.tile_cols = c->width / 8;
     P.tile_row0 = r0;
     P.tile_rows = std::max(0, r1 - r0);
-    P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
+    finish_params(P);
     P.max_depth = c->max_depth;
     P.frame0 = u.frame_count;
     P.n_frames = n_frames;
@@ -203,11 +220,20 @@ int launch(rt_context* c, const RtParams& P, bool record)
     stream_geometry(c, P, &blocks, &threads);
     if (rt_stream_lds_bytes(P.n_pad, threads) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
+    if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
+        return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
+                    P.tile_rows);
     HIP_TRY(hipMemsetAsync(c->d_work, 0, 256, c->stream));
     // The scalar cache serves the sieve faster than LDS while the geometry stream fits in it.
     const bool sgeom = c->kernel == RT_KERNEL_STREAM_SGPR ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES);
     HIP_TRY(rt_launch_stream(P, fused, record, sgeom, blocks, threads, c->stream));
+    if (!record) {
+        // the stream kernel leaves the rgba8 resolve (shader.comp:129-132) to a full-lane pass
+        const unsigned last = P.frame0 + (unsigned)((P.n_frames - 1) * P.frame_stride);
+        HIP_TRY(rt_launch_resolve(P.accum, P.color, P.width, (P.tile_col0 + P.tile_cols) * 8, P.tile_row0 * 8,
+                                  (P.tile_row0 + P.tile_rows) * 8, (float)(int)(last + 1u), c->stream));
+    }
     return RT_OK;
 }
 
@@ -508,7 +534,7 @@ int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_
     P.tile_cols = (x0 + w + 7) / 8 - P.tile_col0;
     P.tile_row0 = y0 / 8;
     P.tile_rows = (y0 + h + 7) / 8 - P.tile_row0;
-    P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
+    finish_params(P);
     P.rec_x0 = x0;
     P.rec_y0 = y0;
     P.rec_w = w;

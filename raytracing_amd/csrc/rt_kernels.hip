@@ -108,9 +108,11 @@ struct Path {
     int bounce;
 };
 
-// shader.comp:73-76,82-94: primary ray of pixel (px,py).
+// shader.comp:73-76,82-90: direction of the camera ray of pixel (px,py).  It depends on the
+// pixel and the camera only, not on the frame, so a pixel computes it once per dispatch.
 template <bool FUSED>
-__device__ __forceinline__ void path_begin(Path& p, const RtParams& P, uint32_t px, uint32_t py)
+__device__ __forceinline__ void primary_direction(const RtParams& P, uint32_t px, uint32_t py,
+                                                  float& dx, float& dy, float& dz)
 {
     const float fw = (float)P.width;
     const float hc = ((float)px * 2.0f - fw) / fw;
@@ -119,8 +121,14 @@ __device__ __forceinline__ void path_begin(Path& p, const RtParams& P, uint32_t 
     const float y = mad<FUSED>(vc, P.up[1], mad<FUSED>(hc, P.right[1], P.fwd[1]));
     const float z = mad<FUSED>(vc, P.up[2], mad<FUSED>(hc, P.right[2], P.fwd[2]));
     const float inv = 1.0f / sqrtf(dot3<FUSED>(x, y, z, x, y, z));
+    dx = x * inv; dy = y * inv; dz = z * inv;
+}
+
+// shader.comp:88-94: state of a path at its start.
+__device__ __forceinline__ void path_reset(Path& p, const RtParams& P, float dx, float dy, float dz)
+{
     p.ox = P.pos[0]; p.oy = P.pos[1]; p.oz = P.pos[2];
-    p.dx = x * inv; p.dy = y * inv; p.dz = z * inv;
+    p.dx = dx; p.dy = dy; p.dz = dz;
     p.cr = p.cg = p.cb = 0.15f;
     p.lr = p.lg = p.lb = 0.0f;
     p.bounce = 0;
@@ -226,7 +234,8 @@ __device__ __forceinline__ void record_light(const RtParams& P, uint32_t px, uin
     P.rec_light[3 * pix + 2] = p.lb;
 }
 
-// shader.comp:126-132 for the last frame of a dispatch.
+// shader.comp:126-132 for the last frame of a dispatch (tile kernel; the stream kernel stores
+// the accumulation texel only and leaves the resolve to rt_resolve_kernel).
 __device__ __forceinline__ void store_pixel(const RtParams& P, uint32_t px, uint32_t py, float4 acc)
 {
     const size_t at = (size_t)py * P.width + px;
@@ -264,6 +273,8 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
     if constexpr (!RECORD)
         if (!clear_at(P, 0, P.frame0)) acc = P.accum[at];
     unsigned nrays = 0;
+    float d0x, d0y, d0z;
+    primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
 
     for (int j = 0; j < P.n_frames; j++) {
         const uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
@@ -271,7 +282,7 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
         rt_record* rec = nullptr;
         if constexpr (RECORD) rec = record_slot(P, px, py, j);
         Path p;
-        path_begin<FUSED>(p, P, px, py);
+        path_reset(p, P, d0x, d0y, d0z);
         bool alive = true;
         // per-wavefront bounce termination: the wave leaves when its last path has ended
         while (__ballot(alive) != 0ull) {
@@ -309,13 +320,14 @@ struct SieveRay {
     v2f no2;               // -(o . o) * (1 - RT_SIEVE_MARGIN)
 };
 
-__device__ __forceinline__ SieveRay sieve_ray(const Path& p, float a)
+__device__ __forceinline__ SieveRay sieve_ray(const Path& p, float a, bool alive)
 {
     const float inv = __builtin_amdgcn_rsqf(a);  // 1 ulp is plenty: the margin absorbs it
     const float nx = p.dx * inv, ny = p.dy * inv, nz = p.dz * inv;
     const float d0 = __builtin_fmaf(nz, p.oz, __builtin_fmaf(ny, p.oy, nx * p.ox));
     const float o2 = __builtin_fmaf(p.oz, p.oz, __builtin_fmaf(p.oy, p.oy, p.ox * p.ox));
-    const float no2 = o2 * (RT_SIEVE_MARGIN - 1.0f);
+    // an idle lane gets -inf here, which makes every sphere's g = -inf: rejected
+    const float no2 = alive ? o2 * (RT_SIEVE_MARGIN - 1.0f) : -__builtin_inff();
     SieveRay r;
     r.nnx = v2f{-nx, -nx}; r.nny = v2f{-ny, -ny}; r.nnz = v2f{-nz, -nz};
     r.d0 = v2f{d0, d0};
@@ -353,9 +365,7 @@ __device__ __forceinline__ void sieve_pair(uint32_t& mask, v4f A, v4f B, const S
 
 // The loads of group n+1 (RT_SIEVE_GROUP pairs) are issued before the arithmetic of group n,
 // so their latency is covered by a group's worth of packed math.
-constexpr int RT_SIEVE_GROUP = 4;
-
-template <class GeomPtr>
+template <int RT_SIEVE_GROUP, class GeomPtr>
 __device__ __forceinline__ uint32_t sieve_chunk(GeomPtr g, const SieveRay& r)
 {
     constexpr int NG = RT_CHUNK / 2 / RT_SIEVE_GROUP;
@@ -384,6 +394,12 @@ __device__ __forceinline__ uint32_t sieve_chunk(GeomPtr g, const SieveRay& r)
 // ds_read_b128), true = global memory through the scalar cache (s_load into SGPRs, which the
 // packed instructions take directly as their one scalar operand).  The walk reads LDS either way.
 typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
+#ifndef RT_GROUP_SGPR
+#define RT_GROUP_SGPR 2
+#endif
+#ifndef RT_GROUP_LDS
+#define RT_GROUP_LDS 4
+#endif
 
 template <bool FUSED, bool RECORD, bool SGEOM>
 __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
@@ -412,6 +428,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned nrays = 0;
+    float d0x = 0.f, d0y = 0.f, d0z = 0.f;  // camera-ray direction of the lane's pixel
     rt_record* rec = nullptr;
     Path p;
     p.ox = p.oy = p.oz = 0.f; p.dx = p.dy = p.dz = 0.f;
@@ -437,9 +454,12 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
             if (!alive && rank < navail) {
                 const uint32_t pix = span_cur + rank;
                 const uint32_t tile = pix >> 6, l = pix & 63u;
-                const uint32_t ty = tile / (uint32_t)P.tile_cols, tx = tile - ty * (uint32_t)P.tile_cols;
+                // tile / tile_cols by multiplication: exact for tile < 2^24 (checked on the host)
+                const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
+                const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
                 px = ((uint32_t)P.tile_col0 + tx) * 8 + (l & 7u);
                 py = ((uint32_t)P.tile_row0 + ty) * 8 + (l >> 3);
+                primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
                 j = 0;
                 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (!RECORD)
@@ -457,7 +477,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
             frame = P.frame0 + (uint32_t)(j * P.frame_stride);
             if (j > 0 && clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (RECORD) rec = record_slot(P, px, py, j);
-            path_begin<FUSED>(p, P, px, py);
+            path_reset(p, P, d0x, d0y, d0z);
             start = false;
         }
 
@@ -466,20 +486,20 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         float best = RT_FLT_MAX;
         int idx = -1;
         {
-            const SieveRay sr = sieve_ray(p, a);
+            const SieveRay sr = sieve_ray(p, a, alive);
             for (int sg = 0; sg < nch; sg += RT_SG_CHUNKS) {
                 const int nsg = min(RT_SG_CHUNKS, nch - sg);
                 uint32_t summary = 0;
                 for (int c = 0; c < nsg; c++) {
                     uint32_t rej;
                     if constexpr (SGEOM)
-                        rej = sieve_chunk((ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK, sr);
+                        rej = sieve_chunk<RT_GROUP_SGPR>((ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK, sr);
                     else
-                        rej = sieve_chunk(reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK, sr);
-                    // bits of padding spheres beyond sphere_count are never candidates
-                    const int nvalid = min(RT_CHUNK, max(0, P.sphere_count - (sg + c) * RT_CHUNK));
-                    const uint32_t valid = nvalid >= 32 ? 0xffffffffu : ~(0xffffffffu >> nvalid);
-                    const uint32_t cand = alive ? (~rej & valid) : 0u;
+                        rej = sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK, sr);
+                    // Idle lanes carry -inf in the sieve constants and reject everything through
+                    // the arithmetic; only the last chunk has spheres beyond sphere_count to mask.
+                    uint32_t cand = ~rej;
+                    if (sg + c == nch - 1) cand &= P.last_chunk_valid;
                     wmask[c * 64 + lane] = cand;
                     summary = (summary << 1) | (cand != 0u ? 1u : 0u);
                 }
@@ -517,7 +537,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                 acc.w = 1.0f + acc.w;
                 j++;
                 if (j == P.n_frames) {
-                    if constexpr (!RECORD) store_pixel(P, px, py, acc);
+                    if constexpr (!RECORD) P.accum[(size_t)py * P.width + px] = acc;
                     alive = false;
                 } else {
                     start = true;
@@ -549,9 +569,9 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
     unsigned bad_s = 0, bad_f = 0, n_exact = 0, n_sieve = 0;
     const float a_s = dot3<false>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
     const float a_f = dot3<true>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
-    const SieveRay sr = sieve_ray(p, a_s);
+    const SieveRay sr = sieve_ray(p, a_s, true);
     for (int ch = 0; ch < P.n_pad / RT_CHUNK; ch++) {
-        const uint32_t rej = sieve_chunk(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
+        const uint32_t rej = sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
         for (int n = 0; n < RT_CHUNK; n++) {
             const int i = ch * RT_CHUNK + n;
             if (i >= P.sphere_count || !live) break;

@@ -34,6 +34,9 @@ struct RtParams {
     int width, height;
     int tile_col0;     // first column of 8x8 tiles rendered
     int tile_cols;     // number of tile columns rendered
+    unsigned tile_cols_magic;  // ceil(2^32 / tile_cols), 0 when tile_cols == 1:
+                               // __umulhi(t, magic) == t / tile_cols while t * tile_cols < 2^32
+    unsigned last_chunk_valid; // bit (31-n) set when sphere n of the last chunk is < sphere_count
     int tile_row0;     // first row of 8x8 tiles rendered
     int tile_rows;     // number of tile rows rendered
     unsigned total_pixels;  // tile_cols * tile_rows * 64
