@@ -102,7 +102,8 @@ int rt_set_uniforms(rt_context* ctx, const void* ubo80);
 /* The literal 50 of res/shaders/shader.comp:95 as a parameter (default 50). */
 int rt_set_max_depth(rt_context* ctx, int max_depth);
 
-/* Float profile (default RT_PROFILE_STRICT) and kernel (default RT_KERNEL_STREAM). */
+/* Float profile (default RT_PROFILE_STRICT) and kernel (default RT_KERNEL_STREAM).  No
+   reference counterpart: the shader source leaves the first open and has one kernel. */
 int rt_set_profile(rt_context* ctx, int profile);
 int rt_set_kernel(rt_context* ctx, int kernel);
 
@@ -112,7 +113,8 @@ int rt_set_kernel(rt_context* ctx, int kernel);
 int rt_set_tile_rows(rt_context* ctx, int row0, int row1);
 
 /* Frame schedule of a multi-frame dispatch: frame j uses
-   frameCount = ubo.frameCount + j*stride (sample split across GPUs). */
+   frameCount = ubo.frameCount + j*stride (sample split across GPUs).  No reference
+   counterpart: Scene::update advances frameCount by one (includes/scene.hpp:107). */
 int rt_set_frame_schedule(rt_context* ctx, int frame_stride, int clear_mode);
 
 /* vkCmdDispatch of shader.comp main() (compute_pipeline.cpp:429-432), asynchronous
@@ -136,7 +138,9 @@ int rt_write_accum(rt_context* ctx, const float* rgba32f);
 int rt_device_buffers(rt_context* ctx, void** accum_dev, void** color_dev);
 
 /* Use caller-owned device memory (W*H*16 / W*H*4 bytes) for the images; NULL
-   returns to the context's own allocations. */
+   returns to the context's own allocations.  The nearest reference counterpart is
+   the per-frame rebinding of the colour image to the acquired swap-chain image
+   (compute_pipeline.cpp:589-655). */
 int rt_bind_buffers(rt_context* ctx, void* accum_dev, void* color_dev);
 
 /* Re-resolve the colour image from the accumulation image with an explicit
@@ -147,19 +151,22 @@ int rt_resolve(rt_context* ctx, float divisor);
 /* Debug twin of rt_dispatch_frames for a crop: traces [x0,x0+w) x [y0,y0+h) and
    writes n_frames*h*w*max_depth records (index ((j*h+y)*w+x)*max_depth+bounce) and,
    if light is non-NULL, n_frames*h*w*3 floats of per-frame `light`.  Does not
-   touch the images. */
+   touch the images.  No reference counterpart (the reference has no test hooks). */
 int rt_trace_crop(rt_context* ctx, int n_frames, int x0, int y0, int w, int h,
                   rt_record* records, float* light);
 
+/* Ray counters, summed in the kernels (no reference counterpart). */
 int rt_get_counters(rt_context* ctx, rt_counters* out);
 int rt_reset_counters(rt_context* ctx);
 
 /* HIP-event timer on the context's stream: begin/end bracket any number of
-   dispatches; rt_timer_end synchronises and returns the elapsed milliseconds. */
+   dispatches; rt_timer_end synchronises and returns the elapsed milliseconds
+   (no reference counterpart; its FPS readout is commented out, src/application.cpp:124-133). */
 int rt_timer_begin(rt_context* ctx);
 int rt_timer_end(rt_context* ctx, float* ms);
 
-/* Launch geometry of the stream kernel (0 = choose from the device). */
+/* Launch geometry of the stream kernel (0 = choose from the device).  No reference
+   counterpart: the shader's is fixed at local_size 8x8 (res/shaders/shader.comp:2). */
 int rt_set_launch(rt_context* ctx, int blocks, int threads_per_block);
 int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* threads);
 
@@ -192,10 +199,12 @@ int rt_scene_parse(const char* text, size_t len, rt_scene** out);
 int rt_scene_save(const rt_scene* scene, const char* path);
 int rt_scene_free(rt_scene* scene);
 
-/* Scene::spheres() / Scene::camera() (includes/scene.hpp:104-105). */
+/* Scene::spheres() / Scene::camera() (includes/scene.hpp:104-105): the sphere array
+   (count x 32 bytes) and the 80-byte uniform block, mutable like the public members
+   m_spheres / m_camera (scene.hpp:121-122). */
 int rt_scene_sphere_count(const rt_scene* scene);
-void* rt_scene_spheres(rt_scene* scene); /* count x 32 B, mutable like m_spheres */
-void* rt_scene_ubo(rt_scene* scene);     /* 80 B, mutable like m_camera           */
+void* rt_scene_spheres(rt_scene* scene);
+void* rt_scene_ubo(rt_scene* scene);
 
 /* The camera basis Application::Application installs at launch
    (src/application.cpp:10-23) from yaw/pitch in degrees (scene.hpp:127-128). */
@@ -209,7 +218,8 @@ int rt_scene_reset_frame_count(rt_scene* scene); /* scene.hpp:118 */
 /* The public members Scene::acceleration / Scene::velocity (scene.hpp:125-126). */
 int rt_scene_get_motion(const rt_scene* scene, float acceleration[3], float velocity[3]);
 
-/* Seeded synthetic scenes written in the same schema.
+/* Seeded synthetic scenes in the same representation (no reference counterpart beyond the
+   random spheres of src/scene.cpp:21-35).
    kind 0: "rtiow"  -- ground + 22x22 jittered small spheres + 3 large ones;
    kind 1: "cube"   -- `count` spheres with the distributions of src/scene.cpp:21-35. */
 int rt_scene_generate(int kind, int count, uint32_t seed, rt_scene** out);

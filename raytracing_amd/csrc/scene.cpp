@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -83,6 +84,8 @@ void emitVec3(std::string& out, const char* indent, vec3 v)
 
 Scene::Scene() : Scene(defaultPath()) {}
 
+Scene::Scene(NoLoad) { std::memset(static_cast<void*>(&m_camera), 0, sizeof m_camera); }
+
 Scene::Scene(const std::string& p, uint32_t grow_seed) : path(p)
 {
     parseText(readFile(p));
@@ -146,15 +149,20 @@ void Scene::parseText(const std::string& text)
     }
     // includes/scene.hpp:68-78: [position, forward, right, up, sphereCount, ignored]
     if (!camera->is_sequence() || camera->size() != 6) throw SceneError(RT_E_PARSE, "camera is not a 6-sequence");
-    UniformBufferObject cam;
-    cam.camera_position = decodeVec3(camera->items[0], "camera position");
-    cam.camera_forward = decodeVec3(camera->items[1], "camera forward");
-    cam.camera_right = decodeVec3(camera->items[2], "camera right");
-    cam.camera_up = decodeVec3(camera->items[3], "camera up");
-    if (!yaml::to_int(camera->items[4], &cam.sphereCount)) throw SceneError(RT_E_PARSE, "bad camera sphereCount");
-    cam.frameCount = 0;
+    const vec3 position = decodeVec3(camera->items[0], "camera position");
+    const vec3 forward = decodeVec3(camera->items[1], "camera forward");
+    const vec3 right = decodeVec3(camera->items[2], "camera right");
+    const vec3 up = decodeVec3(camera->items[3], "camera up");
+    int count = 0;
+    if (!yaml::to_int(camera->items[4], &count)) throw SceneError(RT_E_PARSE, "bad camera sphereCount");
     m_spheres = std::move(list);
-    m_camera = cam;
+    std::memset(static_cast<void*>(&m_camera), 0, sizeof m_camera);  // padding travels to the device too
+    m_camera.camera_position = position;
+    m_camera.camera_forward = forward;
+    m_camera.camera_right = right;
+    m_camera.camera_up = up;
+    m_camera.sphereCount = count;
+    m_camera.frameCount = 0;
 }
 
 void Scene::update(float dt)

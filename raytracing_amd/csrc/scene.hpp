@@ -30,13 +30,18 @@ float radians(float degrees);
 
 // std140 uniform block of the kernel (reference includes/scene.hpp:22-29): 80 bytes,
 // sphereCount at 60, frameCount at 64.
-struct UniformBufferObject {
-    alignas(16) vec3 camera_forward;
-    alignas(16) vec3 camera_right;
-    alignas(16) vec3 camera_up;
-    alignas(16) vec3 camera_position;
-    alignas(4) int sphereCount = 0;
-    alignas(4) uint32_t frameCount = 0;
+// The padding the reference gets from alignas(16) is spelled out so that copies carry it.
+struct alignas(16) UniformBufferObject {
+    vec3 camera_forward;
+    float _pad0 = 0.f;
+    vec3 camera_right;
+    float _pad1 = 0.f;
+    vec3 camera_up;
+    float _pad2 = 0.f;
+    vec3 camera_position;
+    int sphereCount = 0;
+    uint32_t frameCount = 0;
+    uint32_t _pad3[3] = {0, 0, 0};
 };
 static_assert(sizeof(UniformBufferObject) == 80, "UBO layout");
 
@@ -92,7 +97,7 @@ class Scene {
 
    private:
     struct NoLoad {};
-    explicit Scene(NoLoad) {}
+    explicit Scene(NoLoad);
     void parseText(const std::string& text);
 };
 

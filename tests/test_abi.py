@@ -1,0 +1,65 @@
+"""CPU tests of the C-ABI boundary: the shared library loads without a GPU, exports every symbol
+include/rt_hip.h declares (and the binding declares nothing the header lacks), and refuses to
+run without a device instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "rt_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from raytracing_amd import _native
+
+    names = _declared()
+    assert len(names) >= 40
+    lib = C.CDLL(_native.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the Python binding covers exactly the header
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_every_entry_point_cites_what_it_replaces():
+    """The comment in front of each declaration names the reference file:line it stands in for, or
+    says that the reference has no counterpart (consecutive declarations may share a comment)."""
+    text = open(HEADER).read()
+    body = text[text.index("backend */"):]
+    for m in re.finditer(r"\n(?:int|const char\*|void\*)\s+(rt_[a-z0-9_]+)\s*\(", body):
+        before = body[: m.start()]
+        comment = before[before.rindex("/*"):]
+        assert re.search(r"\.(cpp|hpp|comp|glsl):\d+|no\s+reference\s+counterpart", comment, re.I), m.group(1)
+
+
+def test_no_device_means_an_error_not_a_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import raytracing_amd as rt
+
+    with pytest.raises(rt.RtError) as e:
+        rt.Renderer(64, 64)
+    assert e.value.code == -2 and "no CPU path" in e.value.message
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under raytracing_amd/ may import, link or load the oracle."""
+    pkg = os.path.join(ROOT, "raytracing_amd")
+    for base, _, files in os.walk(pkg):
+        if os.path.basename(base) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "oracle" not in text.lower(), os.path.join(base, f)
