@@ -42,6 +42,9 @@ def parse_args():
     p.add_argument("--kernel", choices=["stream", "tile"], default="stream")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--max-depth", type=int, default=50)
+    p.add_argument("--workload", choices=["rtiow4k", "interactive"], default="rtiow4k",
+                   help="rtiow4k: the headline metric; interactive: 1080p, 1 frame per dispatch, moving camera, "
+                        "screen tiles split across GPUs, ms/frame")
     return p.parse_args()
 
 
@@ -80,6 +83,67 @@ def cpu_baseline(scene, profile, max_depth, seconds):
     }
 
 
+def interactive(args, rank, world, device, backend):
+    """1080p, one frame per dispatch, the default scene with scripted camera impulses fed through
+    Scene::update so that accumulation resets on a known schedule; every rank renders a band of
+    tile rows and rank 0 gathers the rgba8 bands each frame.  A step is one displayed frame."""
+    import torch
+    import torch.distributed as dist
+
+    import raytracing_amd as rt
+    from raytracing_amd.multi_gpu import TileSplit
+
+    w, h = 1920, 1080
+    scene = rt.Scene.default()
+    tiles = TileSplit(rank, world, h)
+    color = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r = rt.Renderer(w, h, device=device)
+    r.bind_buffers(accum.data_ptr(), color.data_ptr())
+    r.set_profile(rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT)
+    r.set_max_depth(args.max_depth)
+    r.upload_spheres(scene.spheres)
+    tiles.apply(r)
+    fwd = scene.camera["camera_forward"][0].copy()
+
+    def frame(i):
+        if i % 40 == 0:  # a key tap: one impulse along the view direction (src/application.cpp:44-47)
+            scene.add_acceleration(*(fwd * 100.0).tolist())
+        scene.update(1.0 / 60.0)
+        r.set_uniforms(scene.camera)
+        r.dispatch(1)
+        r.sync()
+        stage = color.cpu() if (world > 1 and backend != "nccl") else color
+        tiles.gather(stage, dst=0)
+
+    for i in range(args.warmup):
+        frame(i)
+    r.reset_counters()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ms/frame 1080p interactive", "value": float(t[0]) / args.steps * 1e3, "unit": "ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t[0]) / args.steps * 1e3,
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "default scene (40 spheres), 1920x1080, 1 frame per dispatch, camera impulse every "
+                                   "40 frames, host sync + band gather every frame",
+                       "parallelism": f"bands of 8x8-tile rows over {world} GPU(s), rgba8 bands gathered to rank 0"},
+        }), flush=True)
+    r.close()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -94,10 +158,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal hooks for a one-GPU box: RT_BENCH_DEVICE pins every rank to one device and
+    # RT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU).
+    device = int(os.environ.get("RT_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+
+    if args.workload == "interactive":
+        interactive(args, rank, world, device, backend)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     scene = rt.Scene.generate(rt.KIND_RTIOW, 0, SCENE_SEED)
     profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
@@ -107,7 +184,7 @@ def main():
     split = SampleSplit(rank, world)
     accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device="cuda")
     color = torch.zeros((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
-    r = rt.Renderer(WIDTH, HEIGHT, device=local_rank)
+    r = rt.Renderer(WIDTH, HEIGHT, device=device)
     r.bind_buffers(accum.data_ptr(), color.data_ptr())
     r.set_profile(profile)
     r.set_kernel(kernel)
@@ -147,7 +224,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     cnt = r.counters()
-    stats = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["sphere_tests"])], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["sphere_tests"])], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

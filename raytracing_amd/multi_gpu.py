@@ -51,7 +51,14 @@ class SampleSplit:
     def reduce(self, accum, dst: int = 0) -> None:
         """Sum the per-rank accumulation images into rank `dst` (RCCL on GPUs, gloo on CPU)."""
         if self.world > 1:
-            _dist().reduce(accum, dst=dst, op=_dist().ReduceOp.SUM)
+            dist = _dist()
+            if accum.is_cuda and dist.get_backend() == "gloo":  # rehearsal on one GPU: stage through the host
+                host = accum.cpu()
+                dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+                if self.rank == dst:
+                    accum.copy_(host)
+            else:
+                dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
 
     def divisor(self, steps: int, frames_per_step: int) -> float:
         """The shader divides by frameCount + 1 (shader.comp:129); frameCount of the last frame
