@@ -144,6 +144,7 @@ void finish_params(RtParams& P)
 {
     P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
     P.tile_cols_magic = tile_magic(P.tile_cols);
+    P.n_lds = P.n_pad <= RT_MAX_LDS_SPHERES ? P.n_pad : 0;
     const int rem = P.sphere_count - (P.n_pad - RT_CHUNK);  // spheres in the last chunk
     P.last_chunk_valid = (P.n_pad == 0 || rem >= RT_CHUNK) ? 0xffffffffu : ~(0xffffffffu >> rem);
 }
@@ -195,9 +196,9 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
 // LDS one workgroup needs (geometry + per-wave candidate masks).
 void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* threads)
 {
-    int t = c->threads > 0 ? c->threads : (P.n_pad <= 1024 ? 256 : 1024);
+    int t = c->threads > 0 ? c->threads : (P.n_lds <= 1024 ? 256 : 1024);
     t = std::max(64, std::min(1024, t / 64 * 64));
-    const size_t lds = rt_stream_lds_bytes(P.n_pad, t);
+    const size_t lds = rt_stream_lds_bytes(P.n_lds, t);
     int per_cu = std::min<int>(16 / (t / 64), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
     per_cu = std::max(1, per_cu);
     int b = c->blocks > 0 ? c->blocks : c->cu_count * per_cu;
@@ -211,14 +212,14 @@ int launch(rt_context* c, const RtParams& P, bool record)
 {
     if (P.total_pixels == 0) return RT_OK;
     const bool fused = c->profile == RT_PROFILE_FUSED;
-    const bool tile = c->kernel == RT_KERNEL_TILE || P.sphere_count > RT_MAX_LDS_SPHERES;
+    const bool tile = c->kernel == RT_KERNEL_TILE;
     if (tile) {
         HIP_TRY(rt_launch_tile(P, fused, record, c->stream));
         return RT_OK;
     }
     int blocks, threads;
     stream_geometry(c, P, &blocks, &threads);
-    if (rt_stream_lds_bytes(P.n_pad, threads) > kLdsPerCu)
+    if (rt_stream_lds_bytes(P.n_lds, threads) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
@@ -645,7 +646,7 @@ int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t 
     RtParams P;
     int rc = make_params(c, 1, &P);
     if (rc != RT_OK) return rc;
-    if (P.n_pad > RT_MAX_LDS_SPHERES) return fail(RT_E_INVALID, "too many spheres for the sieve audit");
+    if (P.n_lds == 0 && P.n_pad) return fail(RT_E_INVALID, "too many spheres for the sieve audit");
     float* d_rays = nullptr;
     unsigned long long* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 6 * sizeof(float)));

@@ -408,13 +408,15 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    float* radius = reinterpret_cast<float*>(smem + P.n_pad);
-    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) {
+    // Geometry is staged in LDS when it fits (P.n_lds == n_pad); a scene too large for that
+    // (P.n_lds == 0, SGEOM only) is read from global memory by the sieve and the walk alike.
+    float* radius = reinterpret_cast<float*>(smem + P.n_lds);
+    for (int i = threadIdx.x; i < P.n_lds; i += blockDim.x) {
         smem[i] = P.geom[i];
         radius[i] = P.radius[i];
     }
     __syncthreads();  // the only barrier: waves run independently from here on
-    uint32_t* wmask = reinterpret_cast<uint32_t*>(radius + P.n_pad) + wave * (RT_SG_CHUNKS * 64);
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(radius + P.n_lds) + wave * (RT_SG_CHUNKS * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
@@ -519,8 +521,13 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                         const int b = __clz(cur);
                         cur &= ~(0x80000000u >> b);
                         const int i = curbase + b;
-                        const float* f = gf + (i >> 1) * 8 + (i & 1);
-                        test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx);
+                        if (P.n_lds) {
+                            const float* f = gf + (i >> 1) * 8 + (i & 1);
+                            test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx);
+                        } else {
+                            const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
+                            test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx);
+                        }
                     }
                 }
             }
@@ -651,19 +658,23 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t rt_stream_lds_bytes(int n_pad, int threads)
+size_t rt_stream_lds_bytes(int n_lds, int threads)
 {
-    return (size_t)n_pad * (sizeof(float4) + sizeof(float)) +
+    return (size_t)n_lds * (sizeof(float4) + sizeof(float)) +
            (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
 }
 
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, bool sgeom, int blocks, int threads,
                             hipStream_t st)
 {
-    const size_t lds = rt_stream_lds_bytes(P.n_pad, threads);
-    if (record)  // the debug twin always takes the LDS path
+    const size_t lds = rt_stream_lds_bytes(P.n_lds, threads);
+    if (P.n_lds == 0) sgeom = true;  // nothing staged: the sieve must read global memory
+    if (record && P.n_lds)  // the debug twin takes the LDS path when there is one
         return fused ? launch_stream<true, true, false>(P, blocks, threads, lds, st)
                      : launch_stream<false, true, false>(P, blocks, threads, lds, st);
+    if (record)
+        return fused ? launch_stream<true, true, true>(P, blocks, threads, lds, st)
+                     : launch_stream<false, true, true>(P, blocks, threads, lds, st);
     if (sgeom)
         return fused ? launch_stream<true, false, true>(P, blocks, threads, lds, st)
                      : launch_stream<false, false, true>(P, blocks, threads, lds, st);

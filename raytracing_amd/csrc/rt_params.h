@@ -31,6 +31,7 @@ struct RtParams {
     float fwd[3], right[3], up[3], pos[3];
     int sphere_count;  // loop bound of Trace(): ubo.sphereCount
     int n_pad;         // sphere_count rounded up to a multiple of RT_CHUNK
+    int n_lds;         // spheres staged in LDS by the stream kernel: n_pad, or 0 when they do not fit
     int width, height;
     int tile_col0;     // first column of 8x8 tiles rendered
     int tile_cols;     // number of tile columns rendered

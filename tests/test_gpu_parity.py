@@ -252,6 +252,24 @@ def test_sphere_counts_ragged_chunks(rt, count):
         assert cnt["rays"] == crays
 
 
+def test_more_spheres_than_fit_in_lds(rt):
+    """5000 spheres: the stream kernel stages nothing in LDS and reads geometry from global memory."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, 5000, 21)
+    ubo = scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    for profile in (0, 1):
+        acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=profile, kernel=0, n_frames=2, depth=6)
+        cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=profile, n_frames=2, depth=6)
+        assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and cnt["rays"] == crays
+    with rt.Renderer(96, 64) as r:
+        r.set_max_depth(6)
+        r.upload_spheres(scene.spheres)
+        r.set_uniforms(ubo)
+        rec, light = r.trace_crop(1, 40, 24, 16, 8)
+    crec, clight = O.trace_crop(ubo, scene.spheres, 96, 64, 40, 24, 16, 8, max_depth=6)
+    assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(_bits(light), _bits(clight))
+
+
 def test_stress_4096_spheres_crop(rt):
     """Config 'stress4096' (depth 50): records on a crop vs the oracle, both kernels agree on an image."""
     scene = rt.Scene.generate(rt.KIND_CUBE, 4096, 3)
