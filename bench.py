@@ -279,7 +279,7 @@ def main():
                                         / (launch_ms * 1e-3) / 1e9,
             },
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:  # the CPU leg runs at N=1 only
             line["cpu_baseline"] = cpu_baseline(scene, profile, args.max_depth, args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
