@@ -94,6 +94,15 @@ int rt_resize(rt_context* ctx, int width, int height);
    into the device geometry / albedo streams.  Call again only when spheres change. */
 int rt_upload_spheres(rt_context* ctx, const void* spheres_aos32, int count);
 
+/* Material extension.  No reference counterpart: the shader has one surface response
+   (res/shaders/shader.comp:105-118) and its Sphere has no material field; the sampling
+   primitive is the shader's unused random_unit_vector (res/shaders/def.glsl:65-73).
+   kind_param holds {kind, param} per uploaded sphere: kind 0 = the reference response,
+   1 = lambertian, 2 = metal (param = fuzz), 3 = dielectric (param = index of refraction).
+   count must equal the uploaded sphere count; count 0 (or NULL) switches the extension
+   off.  rt_upload_spheres also switches it off. */
+int rt_upload_materials(rt_context* ctx, const float* kind_param, int count);
+
 /* UBO half of updateScene (compute_pipeline.cpp:492-493): the 80-byte
    UniformBufferObject (includes/scene.hpp:22-29; sphereCount at byte 60,
    frameCount at byte 64). */
@@ -206,6 +215,12 @@ int rt_scene_sphere_count(const rt_scene* scene);
 void* rt_scene_spheres(rt_scene* scene);
 void* rt_scene_ubo(rt_scene* scene);
 
+/* Material extension (no reference counterpart): count x {kind, param} floats, parallel to
+   the sphere array, mutable.  In the scene file a sphere may carry a 4th element
+   `[kind, param]`; the reference's decoder (includes/scene.hpp:89-95) accepts exactly three,
+   and save() writes the 4th only for spheres whose kind is not 0. */
+float* rt_scene_materials(rt_scene* scene);
+
 /* The camera basis Application::Application installs at launch
    (src/application.cpp:10-23) from yaw/pitch in degrees (scene.hpp:127-128). */
 int rt_scene_set_orientation(rt_scene* scene, float yaw_deg, float pitch_deg);
@@ -221,7 +236,8 @@ int rt_scene_get_motion(const rt_scene* scene, float acceleration[3], float velo
 /* Seeded synthetic scenes in the same representation (no reference counterpart beyond the
    random spheres of src/scene.cpp:21-35).
    kind 0: "rtiow"  -- ground + 22x22 jittered small spheres + 3 large ones;
-   kind 1: "cube"   -- `count` spheres with the distributions of src/scene.cpp:21-35. */
+   kind 1: "cube"   -- `count` spheres with the distributions of src/scene.cpp:21-35;
+   kind 2: kind 0 with the material extension (glass / matte / metal) switched on. */
 int rt_scene_generate(int kind, int count, uint32_t seed, rt_scene** out);
 
 #ifdef __cplusplus

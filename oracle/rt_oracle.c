@@ -48,6 +48,28 @@ uint8_t rto_unorm8(float v)
     return (uint8_t)floorf(v * 255.0f + 0.5f);
 }
 
+/* sin and cos of 2*pi*u for u in [0,1]: quadrant reduction + the classic single-precision
+   minimax polynomials on [-pi/4, pi/4], every step an explicit fmaf, so the GPU kernels
+   (which evaluate the same sequence) give the same bits.  out = {cos, sin}. */
+void rto_sincos_2pi(float u, float out[2])
+{
+    float k = floorf(__builtin_fmaf(u, 4.0f, 0.5f));
+    float f = __builtin_fmaf(k, -0.25f, u);
+    float th = f * 6.283185307179586f;
+    float z = th * th;
+    float sp = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float sn = __builtin_fmaf(sp * z, th, th);
+    float cp = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                              4.166664568298827e-2f);
+    float cn = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    switch ((int)k & 3) {
+        case 0: out[0] = cn;  out[1] = sn;  break;
+        case 1: out[0] = -sn; out[1] = cn;  break;
+        case 2: out[0] = -cn; out[1] = -sn; break;
+        default: out[0] = sn; out[1] = -cn; break;
+    }
+}
+
 /* ---- the two float profiles --------------------------------------------- */
 
 #define PFX(n) strict_##n
@@ -63,7 +85,7 @@ uint8_t rto_unorm8(float v)
 #undef MAD
 
 typedef int (*shade_fn)(const rto_ubo*, const rto_sphere*, int, int, int, int, int, int32_t,
-                        float*, rto_record*);
+                        float*, rto_record*, const float*);
 
 /* One row of 8x8 tiles, every frame of the job, for one float profile.  The
    fused copy is cloned for CPUs with an FMA unit so fmaf() is one instruction
@@ -85,7 +107,7 @@ typedef int (*shade_fn)(const rto_ubo*, const rto_sphere*, int, int, int, int, i
                     if (clear) acc[0] = acc[1] = acc[2] = acc[3] = 0.0f; /* shader.comp:79-81 */ \
                     float light[3];                                                              \
                     rays += (uint64_t)SHADE(ubo, spheres, W, H, job->max_depth, x, y, frame,    \
-                                            light, NULL);                                        \
+                                            light, NULL, job->materials);                        \
                     /* shader.comp:126-128: vec4(light, 1.0) + accumulated */                    \
                     acc[0] = light[0] + acc[0];                                                  \
                     acc[1] = light[1] + acc[1];                                                  \
@@ -186,7 +208,7 @@ int rto_trace_crop(const rto_ubo* ubo, const rto_sphere* spheres, int n_buffer_s
                 size_t p = ((size_t)j * h + (size_t)(y - y0)) * w + (size_t)(x - x0);
                 float light[3];
                 shade(ubo, spheres, job->width, job->height, job->max_depth, x, y, frame, light,
-                      out + p * (size_t)job->max_depth);
+                      out + p * (size_t)job->max_depth, job->materials);
                 if (light_out) memcpy(light_out + 3 * p, light, sizeof light);
             }
     }

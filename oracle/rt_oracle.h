@@ -81,6 +81,7 @@ typedef struct rto_job {
     int frame_stride;         /* frame j uses frameCount = ubo.frameCount + j*stride     */
     int clear_mode;           /* RTO_CLEAR_*                                             */
     int n_threads;            /* host threads (<=1: run on the calling thread)          */
+    const float* materials;   /* material extension: {kind, param} per sphere, or NULL    */
 } rto_job;
 
 /* def.glsl:40-48 */
@@ -112,6 +113,9 @@ int rto_render(const rto_ubo* ubo, const rto_sphere* spheres, int n_buffer_spher
 int rto_trace_crop(const rto_ubo* ubo, const rto_sphere* spheres, int n_buffer_spheres,
                    const rto_job* job, int x0, int y0, int w, int h,
                    rto_record* out, float* light_out);
+
+/* {cos, sin} of 2*pi*u, u in [0,1], by a fixed fmaf sequence (material extension). */
+void rto_sincos_2pi(float u, float out[2]);
 
 /* rgba8 store of shader.comp:132: clamp to [0,1] (NaN -> 0), floor(v*255 + 0.5). */
 uint8_t rto_unorm8(float v);

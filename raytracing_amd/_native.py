@@ -39,6 +39,7 @@ SIGNATURES = {
     "rt_destroy": (C.c_int, [_P]),
     "rt_resize": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_upload_spheres": (C.c_int, [_P, _P, C.c_int]),
+    "rt_upload_materials": (C.c_int, [_P, _P, C.c_int]),
     "rt_set_uniforms": (C.c_int, [_P, _P]),
     "rt_set_max_depth": (C.c_int, [_P, C.c_int]),
     "rt_set_profile": (C.c_int, [_P, C.c_int]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "rt_scene_sphere_count": (C.c_int, [_P]),
     "rt_scene_spheres": (C.c_void_p, [_P]),
     "rt_scene_ubo": (C.c_void_p, [_P]),
+    "rt_scene_materials": (C.c_void_p, [_P]),
     "rt_scene_set_orientation": (C.c_int, [_P, C.c_float, C.c_float]),
     "rt_scene_update": (C.c_int, [_P, C.c_float]),
     "rt_scene_add_acceleration": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),

@@ -68,6 +68,9 @@ struct rt_context {
     RtSphereAos* d_spheres = nullptr;  // AoS copy
     float4* d_geom = nullptr;  // pair-packed sieve geometry
     float* d_radius = nullptr; // radii, padded
+    float2* d_materials = nullptr;  // material extension: {kind, param} per sphere
+    int material_cap = 0;
+    bool have_materials = false;    // true when some sphere has a kind other than 0
     int n_spheres = 0;   // spheres in the buffer (Scene::spheres().size())
     int sphere_cap = 0;  // allocated entries (multiple of RT_CHUNK)
 
@@ -184,6 +187,7 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     P.spheres = c->d_spheres;
     P.geom = c->d_geom;
     P.radius = c->d_radius;
+    P.materials = c->have_materials ? c->d_materials : nullptr;
     P.accum = c->accum;
     P.color = c->color;
     P.work_counter = c->d_work;
@@ -293,6 +297,7 @@ int rt_destroy(rt_context* c)
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_radius) (void)hipFree(c->d_radius);
+    if (c->d_materials) (void)hipFree(c->d_materials);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -359,6 +364,39 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     HIP_TRY(hipMemcpy(c->d_geom, geom.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_radius, radius.data(), (size_t)cap * sizeof(float), hipMemcpyHostToDevice));
     c->n_spheres = count;
+    c->have_materials = false;  // materials belong to a sphere list: upload them again
+    return RT_OK;
+}
+
+int rt_upload_materials(rt_context* c, const float* kind_param, int count)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (count == 0 || !kind_param) {  // back to the reference's single surface response
+        c->have_materials = false;
+        return RT_OK;
+    }
+    if (count != c->n_spheres)
+        return fail(RT_E_INVALID, "%d materials for %d uploaded spheres", count, c->n_spheres);
+    bool any = false;
+    for (int i = 0; i < count; i++) {
+        const float kind = kind_param[2 * i], param = kind_param[2 * i + 1];
+        if (!(kind == 0.0f || kind == 1.0f || kind == 2.0f || kind == 3.0f))
+            return fail(RT_E_INVALID, "material %d: unknown kind %g", i, (double)kind);
+        if (kind == 3.0f && !(param > 0.0f))
+            return fail(RT_E_INVALID, "material %d: a dielectric needs a positive index of refraction", i);
+        any = any || kind != 0.0f;
+    }
+    if (count > c->material_cap) {
+        if (c->d_materials) HIP_TRY(hipFree(c->d_materials));
+        c->d_materials = nullptr;
+        c->material_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_materials, (size_t)count * sizeof(float2)));
+        c->material_cap = count;
+    }
+    HIP_TRY(hipMemcpy(c->d_materials, kind_param, (size_t)count * sizeof(float2), hipMemcpyHostToDevice));
+    c->have_materials = any;
     return RT_OK;
 }
 

@@ -134,6 +134,92 @@ __device__ __forceinline__ void path_reset(Path& p, const RtParams& P, float dx,
     p.bounce = 0;
 }
 
+// {cos, sin} of 2*pi*u for u in [0,1]: quadrant reduction and the classic single-precision
+// minimax polynomials on [-pi/4, pi/4], every step an explicit fma, so that a CPU evaluating
+// the same sequence gets the same bits (the device's own sinf/cosf could not promise that).
+__device__ __forceinline__ void sincos_2pi(float u, float& c, float& s)
+{
+    const float k = floorf(__builtin_fmaf(u, 4.0f, 0.5f));
+    const float f = __builtin_fmaf(k, -0.25f, u);
+    const float th = f * 6.283185307179586f;
+    const float z = th * th;
+    const float sp = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(sp * z, th, th);
+    const float cp = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                                    4.166664568298827e-2f);
+    const float cn = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    c = q == 0 ? cn : q == 1 ? -sn : q == 2 ? -cn : sn;
+    s = q == 0 ? sn : q == 1 ? cn : q == 2 ? -sn : -cn;
+}
+
+// Material extension (no counterpart in the reference, whose one surface response is kind 0):
+// scatter at a hit for kind 1 (lambertian), 2 (metal, param = fuzz) and 3 (dielectric, param =
+// index of refraction), built on the sampling primitive of res/shaders/def.glsl:65-73
+// (random_unit_vector: z = 2*rand(i)-1, a = 2*pi*rand(i+1)).  h = hit point, n = unit normal,
+// r0/r1 drive the unit vector, r2 the reflect/refract choice.  Returns false when the ray is
+// absorbed (the path ends without a sky term).
+template <bool FUSED>
+__device__ __forceinline__ bool scatter(Path& p, int kind, float param, float hx, float hy, float hz,
+                                        float nx, float ny, float nz, float r0, float r1, float r2)
+{
+    float cs, sn;
+    sincos_2pi(r1, cs, sn);
+    const float z = mad<FUSED>(r0, 2.0f, -1.0f);
+    const float rr = sqrtf(fmaxf(mad<FUSED>(-z, z, 1.0f), 0.0f));
+    const float vx = rr * cs, vy = rr * sn, vz = z;  // random_unit_vector
+    const float dinv = 1.0f / sqrtf(dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz));
+    const float ux = p.dx * dinv, uy = p.dy * dinv, uz = p.dz * dinv;
+    if (kind == 1) {  // lambertian: normalize(n + unit vector)
+        float dx = nx + vx, dy = ny + vy, dz = nz + vz;
+        const float dd = dot3<FUSED>(dx, dy, dz, dx, dy, dz);
+        if (dd < 1e-12f) {
+            dx = nx; dy = ny; dz = nz;
+        } else {
+            const float inv = 1.0f / sqrtf(dd);
+            dx *= inv; dy *= inv; dz *= inv;
+        }
+        p.ox = mad<FUSED>(nx, 0.0001f, hx); p.oy = mad<FUSED>(ny, 0.0001f, hy); p.oz = mad<FUSED>(nz, 0.0001f, hz);
+        p.dx = dx; p.dy = dy; p.dz = dz;
+        return true;
+    }
+    if (kind == 2) {  // metal: reflect(unit d, n) + fuzz * unit vector; absorbed below the surface
+        const float k2 = 2.0f * dot3<FUSED>(nx, ny, nz, ux, uy, uz);
+        const float dx = mad<FUSED>(param, vx, mad<FUSED>(-k2, nx, ux));
+        const float dy = mad<FUSED>(param, vy, mad<FUSED>(-k2, ny, uy));
+        const float dz = mad<FUSED>(param, vz, mad<FUSED>(-k2, nz, uz));
+        p.ox = mad<FUSED>(nx, 0.0001f, hx); p.oy = mad<FUSED>(ny, 0.0001f, hy); p.oz = mad<FUSED>(nz, 0.0001f, hz);
+        if (!(dot3<FUSED>(dx, dy, dz, nx, ny, nz) > 0.0f)) return false;
+        p.dx = dx; p.dy = dy; p.dz = dz;
+        return true;
+    }
+    // dielectric: Schlick reflectance, Snell refraction
+    const float dn = dot3<FUSED>(ux, uy, uz, nx, ny, nz);
+    const bool front = dn < 0.0f;
+    const float fx = front ? nx : -nx, fy = front ? ny : -ny, fz = front ? nz : -nz;
+    const float ri = front ? 1.0f / param : param;
+    const float cosv = fminf(-dot3<FUSED>(ux, uy, uz, fx, fy, fz), 1.0f);
+    const float sinv = sqrtf(fmaxf(mad<FUSED>(-cosv, cosv, 1.0f), 0.0f));
+    const float q = (1.0f - ri) / (1.0f + ri);
+    const float q2 = q * q;
+    const float x = 1.0f - cosv;
+    const float x2 = x * x;
+    const float x5 = (x2 * x2) * x;
+    const float reflectance = mad<FUSED>(1.0f - q2, x5, q2);
+    if (ri * sinv > 1.0f || reflectance > r2) {
+        const float k2 = 2.0f * dot3<FUSED>(fx, fy, fz, ux, uy, uz);
+        p.dx = mad<FUSED>(-k2, fx, ux); p.dy = mad<FUSED>(-k2, fy, uy); p.dz = mad<FUSED>(-k2, fz, uz);
+        p.ox = mad<FUSED>(fx, 0.0001f, hx); p.oy = mad<FUSED>(fy, 0.0001f, hy); p.oz = mad<FUSED>(fz, 0.0001f, hz);
+    } else {
+        const float ex = ri * mad<FUSED>(cosv, fx, ux), ey = ri * mad<FUSED>(cosv, fy, uy),
+                    ez = ri * mad<FUSED>(cosv, fz, uz);
+        const float par = sqrtf(fabsf(1.0f - dot3<FUSED>(ex, ey, ez, ex, ey, ez)));
+        p.dx = mad<FUSED>(-par, fx, ex); p.dy = mad<FUSED>(-par, fy, ey); p.dz = mad<FUSED>(-par, fz, ez);
+        p.ox = mad<FUSED>(fx, -0.0001f, hx); p.oy = mad<FUSED>(fy, -0.0001f, hy); p.oz = mad<FUSED>(fz, -0.0001f, hz);
+    }
+    return true;
+}
+
 // shader.comp:97-118 after one Trace(): returns true when the path has ended.
 // idx/t are the nearest hit (idx < 0: miss).
 template <bool FUSED, bool RECORD>
@@ -161,6 +247,31 @@ __device__ __forceinline__ bool path_bounce(Path& p, const RtParams& P, int idx,
     const float nx = pcx * ninv, ny = pcy * ninv, nz = pcz * ninv;
 
     const uint32_t s = rng_seed(px, py, frame, (uint32_t)p.bounce);
+    if (P.materials != nullptr) {  // wave-uniform: the extension costs nothing when it is off
+        const float2 m = P.materials[idx];
+        const int kind = (int)m.x;
+        if (kind != 0) {
+            // rand(i), rand(i+1) for the unit vector (def.glsl:67-68), rand at pixel+(1,0) for the choice
+            const uint32_t m0 = wang_hash(s), m1 = wang_hash(s + 1920u * 1080u * 256u), m2 = wang_hash(s + 1u);
+            if constexpr (RECORD) if (rec) {
+                rec[p.bounce].hit = idx;
+                rec[p.bounce].hash[0] = m0;
+                rec[p.bounce].hash[1] = m1;
+                rec[p.bounce].hash[2] = m2;
+            }
+            p.cr *= col.x; p.cg *= col.y; p.cb *= col.z;
+            if (idx <= 2) {
+                p.lr = mad<FUSED>(2.0f, col.x, p.lr);
+                p.lg = mad<FUSED>(2.0f, col.y, p.lg);
+                p.lb = mad<FUSED>(2.0f, col.z, p.lb);
+            }
+            if (!scatter<FUSED>(p, kind, m.y, hx, hy, hz, nx, ny, nz, hash_to_float(m0), hash_to_float(m1),
+                                hash_to_float(m2)))
+                return true;
+            p.bounce++;
+            return p.bounce >= P.max_depth;
+        }
+    }
     const uint32_t h0 = wang_hash(s), h1 = wang_hash(s + 1u), h2 = wang_hash(s + 1920u);
     if constexpr (RECORD) if (rec) {
         rec[p.bounce].hit = idx;

@@ -52,6 +52,7 @@ struct RtParams {
     const RtSphereAos* spheres;  // AoS copy, read for centre/albedo of the winning sphere
     const float4* geom;          // pair-packed sieve geometry: {cx0,cx1,cy0,cy1},{cz0,cz1,w0,w1}
     const float* radius;         // radii, n_pad entries (read by the literal test of the walk)
+    const float2* materials;     // material extension: {kind, param} per sphere; null = all kind 0
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
     unsigned* work_counter;      // zeroed before every stream-kernel launch

@@ -113,6 +113,7 @@ Scene::Scene(const std::string& p, uint32_t grow_seed) : path(p)
         m_spheres[1].center = vec3(20.0f, 20.0f, 0.0f);
         m_spheres[1].radius = 10.0f;
     }
+    syncMaterials();
 }
 
 Scene Scene::fromText(const std::string& text)
@@ -137,15 +138,29 @@ void Scene::parseText(const std::string& text)
     if (!camera) throw SceneError(RT_E_PARSE, "scene YAML: no 'camera' entry");
 
     std::vector<Sphere> list;
+    std::vector<Material> materials;
     list.reserve(spheres->size());
+    materials.reserve(spheres->size());
     for (const yaml::Node& n : spheres->items) {
-        // includes/scene.hpp:89-95: [center, radius, color]
+        // includes/scene.hpp:89-95: [center, radius, color]; the material extension allows a
+        // 4th element [kind, param]
         Sphere s;
-        if (!n.is_sequence() || n.size() != 3) throw SceneError(RT_E_PARSE, "sphere is not a 3-sequence");
+        Material m;
+        if (!n.is_sequence() || (n.size() != 3 && n.size() != 4))
+            throw SceneError(RT_E_PARSE, "sphere is not a 3-sequence");
         s.center = decodeVec3(n.items[0], "sphere center");
         if (!yaml::to_float(n.items[1], &s.radius)) throw SceneError(RT_E_PARSE, "bad sphere radius");
         s.color = decodeVec3(n.items[2], "sphere color");
+        if (n.size() == 4) {
+            const yaml::Node& mat = n.items[3];
+            if (!mat.is_sequence() || mat.size() != 2 || !yaml::to_float(mat.items[0], &m.kind) ||
+                !yaml::to_float(mat.items[1], &m.param) ||
+                !(m.kind == 0.f || m.kind == 1.f || m.kind == 2.f || m.kind == 3.f) ||
+                (m.kind == 3.f && !(m.param > 0.f)))
+                throw SceneError(RT_E_PARSE, "bad sphere material: expected [kind 0..3, param] (index of refraction > 0 for kind 3)");
+        }
         list.push_back(s);
+        materials.push_back(m);
     }
     // includes/scene.hpp:68-78: [position, forward, right, up, sphereCount, ignored]
     if (!camera->is_sequence() || camera->size() != 6) throw SceneError(RT_E_PARSE, "camera is not a 6-sequence");
@@ -156,6 +171,7 @@ void Scene::parseText(const std::string& text)
     int count = 0;
     if (!yaml::to_int(camera->items[4], &count)) throw SceneError(RT_E_PARSE, "bad camera sphereCount");
     m_spheres = std::move(list);
+    m_materials = std::move(materials);
     std::memset(static_cast<void*>(&m_camera), 0, sizeof m_camera);  // padding travels to the device too
     m_camera.camera_position = position;
     m_camera.camera_forward = forward;
@@ -203,11 +219,16 @@ std::string Scene::toYaml() const
         out += "spheres:\n  []\n";
     } else {
         out += "spheres:\n";
-        for (const Sphere& s : m_spheres) {
+        for (size_t i = 0; i < m_spheres.size(); i++) {
+            const Sphere& s = m_spheres[i];
             out += "  -\n    -\n";
             emitVec3(out, "      ", s.center);
             out += "    - " + yaml::format_float(s.radius) + "\n    -\n";
             emitVec3(out, "      ", s.color);
+            // material extension: a 4th element, only where it says something
+            if (i < m_materials.size() && m_materials[i].kind != 0.f)
+                out += "    -\n      - " + yaml::format_float(m_materials[i].kind) + "\n      - " +
+                       yaml::format_float(m_materials[i].param) + "\n";
         }
     }
     out += "camera:\n";
@@ -261,14 +282,28 @@ Sphere sphere(vec3 c, float r, vec3 col)
 // radius-1000 ground sphere and a 22x22 grid of jittered radius-0.2 spheres, about 488 in
 // all.  The shader has one surface response and lights spheres 0-2, so the three large
 // spheres take those indices.
-Scene makeRtiowScene(uint32_t seed)
+//
+// with_materials = false: every sphere keeps the reference's surface response (kind 0) and the
+// palette only hints at the intended material.  with_materials = true: the material extension
+// assigns glass / matte / metal to the three large spheres, matte to the ground, and
+// matte 80 % / metal 15 % (fuzz U(0,0.5)) / glass 5 % to the small ones.
+Scene makeRtiowScene(uint32_t seed, bool with_materials)
 {
     Scene s = Scene::empty();
     Rng rng(seed);
+    auto mat = [&](float kind, float param) {
+        Material m;
+        if (with_materials) { m.kind = kind; m.param = param; }
+        s.m_materials.push_back(m);
+    };
     s.m_spheres.push_back(sphere(vec3(0.0f, 1.0f, 0.0f), 1.0f, vec3(0.95f, 0.95f, 0.9f)));
+    mat(3.f, 1.5f);
     s.m_spheres.push_back(sphere(vec3(-4.0f, 1.0f, 0.0f), 1.0f, vec3(0.4f, 0.2f, 0.1f)));
+    mat(1.f, 0.f);
     s.m_spheres.push_back(sphere(vec3(4.0f, 1.0f, 0.0f), 1.0f, vec3(0.7f, 0.6f, 0.5f)));
+    mat(2.f, 0.f);
     s.m_spheres.push_back(sphere(vec3(0.0f, -1000.0f, 0.0f), 1000.0f, vec3(0.5f, 0.5f, 0.5f)));
+    mat(1.f, 0.f);
     for (int a = -11; a < 11; a++)
         for (int b = -11; b < 11; b++) {
             const float choose = rng.next();
@@ -277,12 +312,16 @@ Scene makeRtiowScene(uint32_t seed)
                         r4 = rng.next(), r5 = rng.next();
             if (length(c - vec3(4.0f, 0.2f, 0.0f)) <= 0.9f) continue;
             vec3 col;
-            if (choose < 0.8f)
+            if (choose < 0.8f) {
                 col = vec3(r0 * r1, r2 * r3, r4 * r5);  // matte palette
-            else if (choose < 0.95f)
+                mat(1.f, 0.f);
+            } else if (choose < 0.95f) {
                 col = vec3(0.5f + 0.5f * r0, 0.5f + 0.5f * r2, 0.5f + 0.5f * r4);  // metal palette
-            else
-                col = vec3(0.95f, 0.95f, 0.95f);  // glass stand-in
+                mat(2.f, 0.5f * r1);
+            } else {
+                col = vec3(0.95f, 0.95f, 0.95f);  // glass
+                mat(3.f, 1.5f);
+            }
             s.m_spheres.push_back(sphere(c, 0.2f, col));
         }
     s.m_camera.sphereCount = (int)s.m_spheres.size();
@@ -310,6 +349,7 @@ Scene makeCubeScene(int count, uint32_t seed)
     s.m_camera.sphereCount = count;
     s.m_camera.camera_position = vec3(2.1030166f, 5.258916f, -46.312107f);
     s.applyOrientation();
+    s.syncMaterials();
     return s;
 }
 

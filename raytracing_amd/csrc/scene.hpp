@@ -54,6 +54,14 @@ struct Sphere {
 };
 static_assert(sizeof(Sphere) == 32, "Sphere layout");
 
+// Material extension: 0 reference response, 1 lambertian, 2 metal (param = fuzz),
+// 3 dielectric (param = index of refraction).
+struct Material {
+    float kind = 0.f;
+    float param = 0.f;
+};
+static_assert(sizeof(Material) == 8, "Material layout");
+
 struct SceneError : std::runtime_error {
     int code;  // RT_E_IO or RT_E_PARSE
     SceneError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
@@ -86,6 +94,10 @@ class Scene {
 
     std::vector<Sphere> m_spheres;
     UniformBufferObject m_camera;
+    // Material extension (the reference's Sphere has no material): kept parallel to m_spheres by
+    // every loader and generator; kind 0 = the reference's surface response.
+    std::vector<Material> m_materials;
+    void syncMaterials() { m_materials.resize(m_spheres.size()); }
     float mouseSensitivity = 0.25f;
     float movementSpeed = 100.0f;
     vec3 acceleration = vec3(0.0f);
@@ -102,7 +114,7 @@ class Scene {
 };
 
 // Seeded synthetic scenes in the same representation.
-Scene makeRtiowScene(uint32_t seed);
+Scene makeRtiowScene(uint32_t seed, bool with_materials = false);
 Scene makeCubeScene(int count, uint32_t seed);
 
 }  // namespace rt

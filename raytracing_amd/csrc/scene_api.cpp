@@ -83,6 +83,13 @@ void* rt_scene_spheres(rt_scene* s) { return s ? (void*)s->scene.m_spheres.data(
 
 void* rt_scene_ubo(rt_scene* s) { return s ? (void*)&s->scene.m_camera : nullptr; }
 
+float* rt_scene_materials(rt_scene* s)
+{
+    if (!s) return nullptr;
+    s->scene.syncMaterials();
+    return s->scene.m_materials.empty() ? nullptr : &s->scene.m_materials[0].kind;
+}
+
 int rt_scene_set_orientation(rt_scene* s, float yaw_deg, float pitch_deg)
 {
     if (!s) return bad("null argument");
@@ -126,10 +133,10 @@ int rt_scene_generate(int kind, int count, uint32_t seed, rt_scene** out)
 {
     if (!out) return bad("null argument");
     *out = nullptr;
-    if (kind != 0 && kind != 1) return bad("unknown scene kind");
+    if (kind < 0 || kind > 2) return bad("unknown scene kind");
     if (kind == 1 && (count < 0 || count > (1 << 24))) return bad("bad sphere count");
     return guarded([&] {
-        *out = new rt_scene(kind == 0 ? rt::makeRtiowScene(seed) : rt::makeCubeScene(count, seed));
+        *out = new rt_scene(kind == 1 ? rt::makeCubeScene(count, seed) : rt::makeRtiowScene(seed, kind == 2));
         return RT_OK;
     });
 }

@@ -60,6 +60,14 @@ class Renderer:
         ptr = arr.ctypes.data_as(C.c_void_p) if arr.size else None
         N.check(N.lib().rt_upload_spheres(self._h, ptr, int(arr.shape[0]) if arr.size else 0))
 
+    def upload_materials(self, materials: np.ndarray | None) -> None:
+        """Material extension: (n, 2) float32 {kind, param} per uploaded sphere; None switches it off."""
+        if materials is None or len(materials) == 0:
+            N.check(N.lib().rt_upload_materials(self._h, None, 0))
+            return
+        arr = np.ascontiguousarray(materials, np.float32).reshape(-1, 2)
+        N.check(N.lib().rt_upload_materials(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0]))
+
     def set_uniforms(self, ubo: np.ndarray | bytes) -> None:
         raw = ubo.tobytes() if isinstance(ubo, np.ndarray) else bytes(ubo)
         if len(raw) != 80:
@@ -67,8 +75,10 @@ class Renderer:
         N.check(N.lib().rt_set_uniforms(self._h, raw))
 
     def set_scene(self, scene: Scene, frame_count: int | None = None) -> None:
-        """updateScene (compute_pipeline.cpp:491-496): spheres + uniform block."""
+        """updateScene (compute_pipeline.cpp:491-496): spheres + uniform block (+ materials, if any)."""
         self.upload_spheres(scene.spheres)
+        mats = scene.materials
+        self.upload_materials(mats if len(mats) and mats[:, 0].any() else None)
         cam = scene.camera.copy()
         if frame_count is not None:
             cam["frameCount"][0] = frame_count

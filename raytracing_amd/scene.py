@@ -32,6 +32,10 @@ DEFAULT_SCENE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes
 
 KIND_RTIOW = 0
 KIND_CUBE = 1
+KIND_RTIOW_MATERIALS = 2
+
+# material extension: kind 0 = the reference's surface response
+MATERIAL_REFERENCE, MATERIAL_LAMBERTIAN, MATERIAL_METAL, MATERIAL_DIELECTRIC = 0, 1, 2, 3
 
 
 class Scene:
@@ -93,6 +97,16 @@ class Scene:
         ptr = N.lib().rt_scene_ubo(self._h)
         buf = (C.c_char * 80).from_address(ptr)
         return np.frombuffer(buf, dtype=UBO_DTYPE, count=1)
+
+    @property
+    def materials(self) -> np.ndarray:
+        """Material extension: (n, 2) float32 view of {kind, param} per sphere (all zeros = reference)."""
+        n = N.lib().rt_scene_sphere_count(self._h)
+        ptr = N.lib().rt_scene_materials(self._h)
+        if n <= 0 or not ptr:
+            return np.zeros((0, 2), np.float32)
+        buf = (C.c_float * (n * 2)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float32, count=n * 2).reshape(n, 2)
 
     @property
     def sphere_count(self) -> int:

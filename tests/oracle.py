@@ -28,6 +28,7 @@ class Job(C.Structure):
         ("max_depth", C.c_int), ("profile", C.c_int),
         ("n_frames", C.c_int), ("frame_stride", C.c_int),
         ("clear_mode", C.c_int), ("n_threads", C.c_int),
+        ("materials", C.c_void_p),
     ]
 
 
@@ -54,6 +55,8 @@ def lib() -> C.CDLL:
         L.rto_trace_crop.restype = C.c_int
         L.rto_trace_crop.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Job), C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.rto_sincos_2pi.restype = None
+        L.rto_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float)]
         L.rto_camera_basis.restype = None
         L.rto_camera_basis.argtypes = [C.c_float, C.c_float] + [C.POINTER(C.c_float)] * 3
         L.rto_scene_update.restype = None
@@ -70,13 +73,24 @@ def seed(px: int, py: int, frame: int, bounce: int) -> int:
     return int(lib().rto_seed(px, py, frame, bounce))
 
 
-def _job(width, height, max_depth, profile, n_frames, stride, clear, rows, threads) -> Job:
+def _job(width, height, max_depth, profile, n_frames, stride, clear, rows, threads, materials=None) -> Job:
     r0, r1 = rows if rows else (0, 0)
-    return Job(width, height, r0, r1, max_depth, profile, n_frames, stride, clear, threads)
+    ptr = materials.ctypes.data if materials is not None else None
+    return Job(width, height, r0, r1, max_depth, profile, n_frames, stride, clear, threads, ptr)
+
+
+def _materials(materials, n):
+    """(n, 2) float32 {kind, param} per sphere, or None for the reference's surface response."""
+    if materials is None:
+        return None
+    m = np.ascontiguousarray(materials, np.float32).reshape(-1, 2)
+    assert m.shape[0] == n
+    return m
 
 
 def render(ubo: np.ndarray, spheres: np.ndarray, width: int, height: int, *, max_depth=50, profile=STRICT,
-           n_frames=1, frame_stride=1, clear_mode=CLEAR_REFERENCE, rows=None, threads=1, accum=None):
+           n_frames=1, frame_stride=1, clear_mode=CLEAR_REFERENCE, rows=None, threads=1, accum=None,
+           materials=None):
     """Returns (accum HxWx4 f32, color HxWx4 u8, rays).  ubo: 80-byte record array (frameCount = first frame)."""
     ubo_b = np.ascontiguousarray(ubo).tobytes()
     assert len(ubo_b) == 80
@@ -84,7 +98,8 @@ def render(ubo: np.ndarray, spheres: np.ndarray, width: int, height: int, *, max
     acc = np.zeros((height, width, 4), np.float32) if accum is None else np.ascontiguousarray(accum, np.float32).copy()
     col = np.zeros((height, width, 4), np.uint8)
     rays = C.c_uint64()
-    job = _job(width, height, max_depth, profile, n_frames, frame_stride, clear_mode, rows, threads)
+    mats = _materials(materials, len(sph))
+    job = _job(width, height, max_depth, profile, n_frames, frame_stride, clear_mode, rows, threads, mats)
     rc = lib().rto_render(ubo_b, sph.ctypes.data_as(C.c_void_p), len(sph), C.byref(job),
                           acc.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), C.byref(rays))
     if rc:
@@ -93,18 +108,25 @@ def render(ubo: np.ndarray, spheres: np.ndarray, width: int, height: int, *, max
 
 
 def trace_crop(ubo: np.ndarray, spheres: np.ndarray, width: int, height: int, x0, y0, w, h, *, max_depth=50,
-               profile=STRICT, n_frames=1, frame_stride=1):
+               profile=STRICT, n_frames=1, frame_stride=1, materials=None):
     """Returns (records (n_frames,h,w,max_depth), light (n_frames,h,w,3))."""
     ubo_b = np.ascontiguousarray(ubo).tobytes()
     sph = np.ascontiguousarray(spheres)
     rec = np.empty((n_frames, h, w, max_depth), RECORD_DTYPE)
     light = np.empty((n_frames, h, w, 3), np.float32)
-    job = _job(width, height, max_depth, profile, n_frames, frame_stride, CLEAR_REFERENCE, None, 1)
+    mats = _materials(materials, len(sph))
+    job = _job(width, height, max_depth, profile, n_frames, frame_stride, CLEAR_REFERENCE, None, 1, mats)
     rc = lib().rto_trace_crop(ubo_b, sph.ctypes.data_as(C.c_void_p), len(sph), C.byref(job), x0, y0, w, h,
                               rec.ctypes.data_as(C.c_void_p), light.ctypes.data_as(C.c_void_p))
     if rc:
         raise RuntimeError(f"rto_trace_crop failed: {rc}")
     return rec, light
+
+
+def sincos_2pi(u: float):
+    out = (C.c_float * 2)()
+    lib().rto_sincos_2pi(u, out)
+    return float(out[0]), float(out[1])
 
 
 def camera_basis(yaw: float, pitch: float):
