@@ -45,6 +45,9 @@ def parse_args():
     p.add_argument("--workload", choices=["rtiow4k", "interactive"], default="rtiow4k",
                    help="rtiow4k: the headline metric; interactive: 1080p, 1 frame per dispatch, moving camera, "
                         "screen tiles split across GPUs, ms/frame")
+    p.add_argument("--materials", action="store_true",
+                   help="rtiow4k with the material extension (lambertian/metal/dielectric per sphere) switched on; "
+                        "the headline line is quoted without it (the reference has one surface response)")
     return p.parse_args()
 
 
@@ -66,8 +69,9 @@ def cpu_baseline(scene, profile, max_depth, seconds):
     t0 = time.perf_counter()
     while True:
         ubo["frameCount"][0] = frames + 1
+        mats = scene.materials
         acc, _, r = O.render(ubo, scene.spheres, WIDTH, HEIGHT, max_depth=max_depth, profile=profile,
-                             n_frames=1, threads=cores, accum=acc)
+                             n_frames=1, threads=cores, accum=acc, materials=mats if mats[:, 0].any() else None)
         rays += r
         frames += 1
         dt = time.perf_counter() - t0
@@ -176,7 +180,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    scene = rt.Scene.generate(rt.KIND_RTIOW, 0, SCENE_SEED)
+    scene = rt.Scene.generate(rt.KIND_RTIOW_MATERIALS if args.materials else rt.KIND_RTIOW, 0, SCENE_SEED)
     profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
     kernel = rt.KERNEL_TILE if args.kernel == "tile" else rt.KERNEL_STREAM
     fps = args.frames_per_step
@@ -189,7 +193,7 @@ def main():
     r.set_profile(profile)
     r.set_kernel(kernel)
     r.set_max_depth(args.max_depth)
-    r.upload_spheres(scene.spheres)
+    r.set_scene(scene)
 
     def run_steps(n_steps):
         # every pass starts over at frame 1, so warm-up and timed steps do identical work
@@ -261,7 +265,8 @@ def main():
             "config": {
                 "workload": f"rtiow-layout scene seed {SCENE_SEED} ({scene.sphere_count} spheres), {WIDTH}x{HEIGHT}, "
                             f"{fps} frames (spp) per step per GPU, max depth {args.max_depth}, "
-                            f"float profile {args.profile}, kernel {args.kernel}",
+                            f"float profile {args.profile}, kernel {args.kernel}"
+                            + (", material extension on" if args.materials else ""),
                 "parallelism": f"samples split by frame number over {world} GPU(s), one RCCL sum-reduce at the end",
                 "launch": f"{info['blocks']} x {info['threads']}",
             },

@@ -412,3 +412,42 @@ def test_full_size_4k_stream_equals_tile(rt, rtiow_scene):
             assert np.array_equal(_bits(light), _bits(clight))
             # the image holds exactly the sum of the recorded lights, in frame order
             assert np.array_equal(_bits(a_stream[y0:y0 + 8, x0:x0 + 8, :3]), _bits(clight[1] + (clight[0] + np.float32(0.0))))
+
+
+def test_default_scene_1080p_1024_frames(rt, default_scene):
+    """Config '1080p, 1024 accumulated frames, one GPU, depth 50': the whole run on the GPU, the
+    oracle on three bands of tile rows (bit-exact accumulation and colour after 1024 frames),
+    per-bounce records on crops at the first, a middle and the last frame, and the two float
+    profiles against each other over the full image (PSNR >= 50 dB, the stated tolerance)."""
+    w, h, frames = 1920, 1080, 1024
+    images = {}
+    for profile in (0, 1):
+        with rt.Renderer(w, h) as r:
+            r.set_profile(profile)
+            r.set_scene(default_scene, frame_count=1)
+            r.dispatch(frames)
+            images[profile] = (r.read_accum(), r.read_color(), r.counters()["rays"])
+            if profile == 0:
+                for frame, (x0, y0) in [(1, (960, 540)), (512, (700, 300)), (1024, (1201, 777))]:
+                    ubo = default_scene.camera.copy()
+                    ubo["frameCount"][0] = frame
+                    r.set_uniforms(ubo)
+                    rec, light = r.trace_crop(1, x0, y0, 16, 16)
+                    crec, clight = O.trace_crop(ubo, default_scene.spheres, w, h, x0, y0, 16, 16)
+                    assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(rec["hash"], crec["hash"])
+                    assert np.array_equal(_bits(light), _bits(clight))
+    acc, col, rays = images[0]
+    assert np.all(acc[..., 3] == float(frames))
+    total = 0
+    for row in (0, 61, 134):
+        cacc, ccol, crays = _render_cpu(default_scene, w, h, profile=0, n_frames=frames, rows=(row, row + 1))
+        band = slice(row * 8, row * 8 + 8)
+        assert np.array_equal(_bits(acc[band]), _bits(cacc[band])), row
+        assert np.array_equal(col[band], ccol[band]), row
+        total += crays
+    assert 0 < total < rays
+    a = images[0][1][..., :3].astype(np.float64)
+    b = images[1][1][..., :3].astype(np.float64)
+    mse = np.mean((a - b) ** 2)
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    assert psnr >= 50.0, psnr

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ad-hoc timing of the kernels on one GPU (development aid; bench.py is the contract).
 
-usage: python tools/quick_bench.py [scene=rtiow|default|cube4096] [W H] [frames] [reps]
+usage: python tools/quick_bench.py [scene=rtiow|rtiowmat|default|cube4096] [W H] [frames] [reps]
 """
 import os
 import sys
@@ -20,6 +20,8 @@ def main():
     reps = int(a[4]) if len(a) > 4 else 3
     if scene_name == "rtiow":
         scene = rt.Scene.generate(rt.KIND_RTIOW, 0, 7)
+    elif scene_name == "rtiowmat":
+        scene = rt.Scene.generate(rt.KIND_RTIOW_MATERIALS, 0, 7)
     elif scene_name == "default":
         scene = rt.Scene.default()
     else:
@@ -29,8 +31,7 @@ def main():
     ubo = scene.camera.copy()
     ubo["frameCount"][0] = 1
     with rt.Renderer(w, h) as r:
-        r.upload_spheres(scene.spheres)
-        r.set_uniforms(ubo)
+        r.set_scene(scene, frame_count=1)
         print(r.info())
         for kname, kernel in (("lds", 3), ("sgpr", 2), ("tile", 1)):
             for pname, profile in (("strict", 0), ("fused", 1)):
