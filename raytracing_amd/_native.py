@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracing_amd.so")
+# RT_AMD_LIB points at another build of the same library (kernel experiments); default: in-tree
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "libraytracing_amd.so")
 
 
 class RtError(RuntimeError):

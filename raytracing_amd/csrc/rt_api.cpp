@@ -150,6 +150,7 @@ void finish_params(RtParams& P)
     P.n_lds = P.n_pad <= RT_MAX_LDS_SPHERES ? P.n_pad : 0;
     const int rem = P.sphere_count - (P.n_pad - RT_CHUNK);  // spheres in the last chunk
     P.last_chunk_valid = (P.n_pad == 0 || rem >= RT_CHUNK) ? 0xffffffffu : ~(0xffffffffu >> rem);
+    P.last_chunk_count = P.n_pad == 0 ? 0 : std::min(rem, (int)RT_CHUNK);
 }
 
 // Fill the launch-independent part of the kernel arguments; validates state.

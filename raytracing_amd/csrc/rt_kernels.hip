@@ -498,6 +498,23 @@ __device__ __forceinline__ uint32_t sieve_chunk(GeomPtr g, const SieveRay& r)
     return mask;
 }
 
+// The scene's last chunk when it holds fewer than 32 spheres: only the first `ngroups` groups of
+// RT_SIEVE_GROUP pairs are evaluated (no prefetch: one chunk per trace does not pay for it).  The
+// bits of the spheres left out come back as 0, "not rejected"; the caller masks them.
+template <int RT_SIEVE_GROUP, class GeomPtr>
+__device__ __forceinline__ uint32_t sieve_chunk_partial(GeomPtr g, const SieveRay& r, int ngroups)
+{
+    uint32_t mask = 0;
+    for (int n = 0; n < ngroups; n++) {
+        v4f cur[2 * RT_SIEVE_GROUP];
+#pragma unroll
+        for (int k = 0; k < 2 * RT_SIEVE_GROUP; k++) cur[k] = g[n * 2 * RT_SIEVE_GROUP + k];
+#pragma unroll
+        for (int k = 0; k < RT_SIEVE_GROUP; k++) sieve_pair(mask, cur[2 * k], cur[2 * k + 1], r);
+    }
+    return mask << (RT_CHUNK - 2 * RT_SIEVE_GROUP * ngroups);
+}
+
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
 // n_pad*16 B sieve geometry + n_pad*4 B radii + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
 //
@@ -604,15 +621,24 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                 const int nsg = min(RT_SG_CHUNKS, nch - sg);
                 uint32_t summary = 0;
                 for (int c = 0; c < nsg; c++) {
+                    constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
+                    const bool last = sg + c == nch - 1;
+                    constexpr int PGROUP = 2;  // the ragged last chunk goes 2 pairs at a time
+                    const int ngroups = (P.last_chunk_count + 2 * PGROUP - 1) / (2 * PGROUP);
                     uint32_t rej;
-                    if constexpr (SGEOM)
-                        rej = sieve_chunk<RT_GROUP_SGPR>((ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK, sr);
-                    else
-                        rej = sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK, sr);
+                    if constexpr (SGEOM) {
+                        ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
+                        rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
+                                                                     : sieve_chunk<GROUP>(g, sr);
+                    } else {
+                        const v4f* g = reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK;
+                        rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
+                                                                     : sieve_chunk<GROUP>(g, sr);
+                    }
                     // Idle lanes carry -inf in the sieve constants and reject everything through
                     // the arithmetic; only the last chunk has spheres beyond sphere_count to mask.
                     uint32_t cand = ~rej;
-                    if (sg + c == nch - 1) cand &= P.last_chunk_valid;
+                    if (last) cand &= P.last_chunk_valid;
                     wmask[c * 64 + lane] = cand;
                     summary = (summary << 1) | (cand != 0u ? 1u : 0u);
                 }

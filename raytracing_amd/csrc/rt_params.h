@@ -38,6 +38,7 @@ struct RtParams {
     unsigned tile_cols_magic;  // ceil(2^32 / tile_cols), 0 when tile_cols == 1:
                                // __umulhi(t, magic) == t / tile_cols while t * tile_cols < 2^32
     unsigned last_chunk_valid; // bit (31-n) set when sphere n of the last chunk is < sphere_count
+    int last_chunk_count;      // spheres in the last chunk (1..32; 0 for an empty scene)
     int tile_row0;     // first row of 8x8 tiles rendered
     int tile_rows;     // number of tile rows rendered
     unsigned total_pixels;  // tile_cols * tile_rows * 64
