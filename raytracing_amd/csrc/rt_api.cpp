@@ -74,8 +74,8 @@ struct rt_context {
     int n_spheres = 0;   // spheres in the buffer (Scene::spheres().size())
     int sphere_cap = 0;  // allocated entries (multiple of RT_CHUNK)
 
-    unsigned* d_work = nullptr;           // 256-byte block; word 0 is the work counter
-    unsigned long long* d_rays = nullptr; // ray counter
+    unsigned* d_work = nullptr;           // RT_WORK_BYTES: span counters + finished-workgroup count
+    unsigned long long* d_rays = nullptr; // RT_RAY_BYTES: ray counters, summed by rt_get_counters
     uint64_t paths = 0;
 
     unsigned char ubo[80] = {0};
@@ -142,7 +142,7 @@ unsigned tile_magic(int d)
     return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
 }
 
-// Derived fields: call after sphere_count, n_pad and the tile rectangle are set.
+// Derived fields: call after sphere_count, n_pad, n_frames and the tile rectangle are set.
 void finish_params(RtParams& P)
 {
     P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
@@ -151,6 +151,10 @@ void finish_params(RtParams& P)
     const int rem = P.sphere_count - (P.n_pad - RT_CHUNK);  // spheres in the last chunk
     P.last_chunk_valid = (P.n_pad == 0 || rem >= RT_CHUNK) ? 0xffffffffu : ~(0xffffffffu >> rem);
     P.last_chunk_count = P.n_pad == 0 ? 0 : std::min(rem, (int)RT_CHUNK);
+    // A span of a short dispatch (few frames, few spheres) is used up in microseconds, about as
+    // long as the answer to a request for the next one takes: such dispatches ask one span ahead.
+    // Long spans do not: a span held in reserve is a span an idle wave cannot take at the end.
+    P.prefetch = (long long)P.n_frames * std::max(P.n_pad, 32) <= 1024 ? 1 : 0;
 }
 
 // Fill the launch-independent part of the kernel arguments; validates state.
@@ -179,10 +183,10 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     P.tile_cols = c->width / 8;
     P.tile_row0 = r0;
     P.tile_rows = std::max(0, r1 - r0);
+    P.n_frames = n_frames;
     finish_params(P);
     P.max_depth = c->max_depth;
     P.frame0 = u.frame_count;
-    P.n_frames = n_frames;
     P.frame_stride = c->frame_stride;
     P.clear_mode = c->clear_mode;
     P.spheres = c->d_spheres;
@@ -229,17 +233,12 @@ int launch(rt_context* c, const RtParams& P, bool record)
     if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
                     P.tile_rows);
-    HIP_TRY(hipMemsetAsync(c->d_work, 0, 256, c->stream));
+    // d_work (span counters, workgroups finished) is zeroed at creation, and the kernel's last
+    // workgroup zeroes it again on its way out, so no launch needs a memset in front of it.
     // The scalar cache serves the sieve faster than LDS while the geometry stream fits in it.
     const bool sgeom = c->kernel == RT_KERNEL_STREAM_SGPR ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES);
     HIP_TRY(rt_launch_stream(P, fused, record, sgeom, blocks, threads, c->stream));
-    if (!record) {
-        // the stream kernel leaves the rgba8 resolve (shader.comp:129-132) to a full-lane pass
-        const unsigned last = P.frame0 + (unsigned)((P.n_frames - 1) * P.frame_stride);
-        HIP_TRY(rt_launch_resolve(P.accum, P.color, P.width, (P.tile_col0 + P.tile_cols) * 8, P.tile_row0 * 8,
-                                  (P.tile_row0 + P.tile_rows) * 8, (float)(int)(last + 1u), c->stream));
-    }
     return RT_OK;
 }
 
@@ -279,9 +278,10 @@ int rt_create(int device, int width, int height, rt_context** out)
         return bail(fail(RT_E_HIP, "hipStreamCreate failed"));
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipEventCreate failed"));
-    if (hipMalloc(&c->d_work, 256) != hipSuccess || hipMalloc(&c->d_rays, 256) != hipSuccess)
+    if (hipMalloc(&c->d_work, RT_WORK_BYTES) != hipSuccess || hipMalloc(&c->d_rays, RT_RAY_BYTES) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipMalloc failed"));
-    if (hipMemsetAsync(c->d_rays, 0, 256, c->stream) != hipSuccess)
+    if (hipMemsetAsync(c->d_work, 0, RT_WORK_BYTES, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_rays, 0, RT_RAY_BYTES, c->stream) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipMemsetAsync failed"));
     int rc = alloc_images(c, width, height);
     if (rc != RT_OK) return bail(rc);
@@ -615,9 +615,12 @@ int rt_get_counters(rt_context* c, rt_counters* out)
 {
     if (!c || !out) return fail(RT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long rays = 0;
-    HIP_TRY(hipMemcpyAsync(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost, c->stream));
+    static_assert(sizeof(unsigned long long) == 8, "ray counters are 64-bit");
+    unsigned long long slots[RT_RAY_SLOTS * RT_RAY_SLOT_STRIDE];
+    HIP_TRY(hipMemcpyAsync(slots, c->d_rays, RT_RAY_BYTES, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long rays = 0;
+    for (unsigned i = 0; i < RT_RAY_SLOTS; i++) rays += slots[i * RT_RAY_SLOT_STRIDE];
     int count = 0;
     if (c->have_ubo) memcpy(&count, c->ubo + 60, 4);
     out->rays = rays;
@@ -630,7 +633,7 @@ int rt_reset_counters(rt_context* c)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->d_rays, 0, 256, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_rays, 0, RT_RAY_BYTES, c->stream));
     c->paths = 0;
     return RT_OK;
 }

@@ -345,8 +345,7 @@ __device__ __forceinline__ void record_light(const RtParams& P, uint32_t px, uin
     P.rec_light[3 * pix + 2] = p.lb;
 }
 
-// shader.comp:126-132 for the last frame of a dispatch (tile kernel; the stream kernel stores
-// the accumulation texel only and leaves the resolve to rt_resolve_kernel).
+// shader.comp:126-132 for the last frame of a dispatch.
 __device__ __forceinline__ void store_pixel(const RtParams& P, uint32_t px, uint32_t py, float4 acc)
 {
     const size_t at = (size_t)py * P.width + px;
@@ -362,12 +361,15 @@ __device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-__device__ __forceinline__ void add_rays(const RtParams& P, unsigned nrays)
+// One addition per wave, into one of RT_RAY_SLOTS counters a cache line apart (the host adds
+// them up): the waves of a launch finish together, and on a single address their additions
+// would complete one after the other.
+__device__ __forceinline__ void add_rays(const RtParams& P, unsigned nrays, unsigned slot)
 {
     unsigned long long v = nrays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(P.rays, v);
+    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(P.rays + (slot % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE, v);
 }
 
 // ---------------------------------------------------------------- tile kernel
@@ -417,7 +419,7 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
     }
     if constexpr (!RECORD) {
         store_pixel(P, px, py, acc);
-        add_rays(P, nrays);
+        add_rays(P, nrays, blockIdx.x + blockIdx.y);
     }
 }
 
@@ -548,9 +550,37 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
-    // wave-uniform work span
+    // wave-uniform work span.  Spans of RT_SPAN pixels are dealt round-robin into RT_QUEUES
+    // queues, each with a counter on a cache line of its own: atomics on one address complete
+    // one at a time (~10 ns each), and with a single counter the thousands of requests of a
+    // short frame would take longer than its arithmetic.  A wave draws from the queue of its
+    // workgroup (workgroups go round-robin over the XCDs, so that is one queue per XCD) and moves
+    // on to the next queue when one runs dry.
+    const uint32_t nspans = (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
+    uint32_t queue = blockIdx.x % RT_QUEUES, queues_left = RT_QUEUES;
     uint32_t span_cur = 0, span_end = 0;
     bool exhausted = false;
+    // Lane 0 asks a queue for its next span; the answer is left in a vector register so that
+    // nobody waits for it before it is needed.
+    auto ask = [&](uint32_t q) -> uint32_t {
+        const uint32_t qcount = (nspans + RT_QUEUES - 1 - q) / RT_QUEUES;
+        unsigned* counter = P.work_counter + q * RT_QUEUE_STRIDE;
+        uint32_t k = 0xffffffffu;
+        if (lane == 0) {
+            // another workgroup's queue: look first, a plain load does not line up behind atomics
+            if (queues_left == RT_QUEUES ||
+                __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qcount)
+                k = atomicAdd(counter, 1u);
+        }
+        return k;
+    };
+    uint32_t ahead = 0xffffffffu;
+    bool have_ahead = false;
+#ifdef RT_PREFETCH_FORCE
+    const bool prefetch = RT_PREFETCH_FORCE != 0;
+#else
+    const bool prefetch = P.prefetch != 0;
+#endif
 
     // lane state
     bool alive = false, start = false;
@@ -569,15 +599,25 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         unsigned long long freem = __ballot(!alive);
         while (freem != 0ull && !exhausted) {
             if (span_cur == span_end) {
-                uint32_t s0 = 0;
-                if (lane == 0) s0 = atomicAdd(P.work_counter, RT_SPAN);
-                s0 = __builtin_amdgcn_readfirstlane(s0);
-                if (s0 >= P.total_pixels) {
-                    exhausted = true;
-                    break;
+                // spans q, q + RT_QUEUES, ... belong to queue q
+                const uint32_t qcount = (nspans + RT_QUEUES - 1 - queue) / RT_QUEUES;
+                const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
+                have_ahead = false;
+                if (k >= qcount) {
+                    if (--queues_left == 0) {
+                        exhausted = true;
+                        break;
+                    }
+                    queue = (queue + 1) % RT_QUEUES;
+                    continue;
                 }
-                span_cur = s0;
-                span_end = min(s0 + RT_SPAN, P.total_pixels);
+                span_cur = (k * RT_QUEUES + queue) * RT_SPAN;
+                span_end = min(span_cur + RT_SPAN, P.total_pixels);
+                if (prefetch) {
+                    // short spans: ask for the next one now and read the answer when this one is used up
+                    ahead = ask(queue);
+                    have_ahead = true;
+                }
             }
             const uint32_t navail = span_end - span_cur;
             const uint32_t rank = mbcnt64(freem);
@@ -681,7 +721,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                 acc.w = 1.0f + acc.w;
                 j++;
                 if (j == P.n_frames) {
-                    if constexpr (!RECORD) P.accum[(size_t)py * P.width + px] = acc;
+                    if constexpr (!RECORD) store_pixel(P, px, py, acc);
                     alive = false;
                 } else {
                     start = true;
@@ -689,7 +729,24 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
             }
         }
     }
-    if constexpr (!RECORD) add_rays(P, nrays);
+    if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave);
+
+    // The last workgroup to get here puts the work counters back to zero for the next launch:
+    // every other workgroup has already seen them run out, so nobody reads them again.  "Last"
+    // is found in two steps, per queue and then over the queues, to keep the additions of
+    // workgroups that finish together on different addresses.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned q = blockIdx.x % RT_QUEUES;
+        const unsigned in_queue = (gridDim.x - q + RT_QUEUES - 1) / RT_QUEUES;  // workgroups of this queue
+        unsigned* all_done = P.work_counter + RT_QUEUES * RT_QUEUE_STRIDE;
+        unsigned* queue_done = all_done + (1 + q) * RT_QUEUE_STRIDE;
+        if (atomicAdd(queue_done, 1u) == in_queue - 1) {
+            const unsigned nqueues = min(gridDim.x, (unsigned)RT_QUEUES);
+            if (atomicAdd(all_done, 1u) == nqueues - 1)
+                for (unsigned i = 0; i <= 2 * RT_QUEUES; i++) atomicExch(P.work_counter + i * RT_QUEUE_STRIDE, 0u);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- sieve audit

@@ -24,7 +24,23 @@ constexpr int RT_MAX_SGPR_SPHERES = 2048;
 // Relative safety margin of the sieve (2^-16 = 256 ulp): see sieve_chunk in rt_kernels.hip.
 constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
 // Pixels a wave takes from the shared work counter at a time.
-constexpr unsigned RT_SPAN = 256;
+#ifndef RT_SPAN_PIXELS
+#define RT_SPAN_PIXELS 64
+#endif
+constexpr unsigned RT_SPAN = RT_SPAN_PIXELS;
+// Work queues of the stream kernel: RT_QUEUES span counters RT_QUEUE_STRIDE words apart (one
+// cache line each), followed by the count of finished queues and RT_QUEUES counts of finished
+// workgroups.
+#ifndef RT_QUEUES
+#define RT_QUEUES 8
+#endif
+constexpr unsigned RT_QUEUE_STRIDE = 32;
+constexpr unsigned RT_WORK_BYTES = 16384;
+static_assert((2 * RT_QUEUES + 1) * RT_QUEUE_STRIDE * 4 <= RT_WORK_BYTES, "work block too small");
+// Ray counters: RT_RAY_SLOTS 64-bit words RT_RAY_SLOT_STRIDE words (one cache line) apart.
+constexpr unsigned RT_RAY_SLOTS = 32;
+constexpr unsigned RT_RAY_SLOT_STRIDE = 16;
+constexpr unsigned RT_RAY_BYTES = RT_RAY_SLOTS * RT_RAY_SLOT_STRIDE * 8;
 
 struct RtParams {
     // camera (reference UBO, includes/scene.hpp:22-29)
@@ -39,6 +55,7 @@ struct RtParams {
                                // __umulhi(t, magic) == t / tile_cols while t * tile_cols < 2^32
     unsigned last_chunk_valid; // bit (31-n) set when sphere n of the last chunk is < sphere_count
     int last_chunk_count;      // spheres in the last chunk (1..32; 0 for an empty scene)
+    int prefetch;              // stream kernel: waves ask for their next span one span ahead
     int tile_row0;     // first row of 8x8 tiles rendered
     int tile_rows;     // number of tile rows rendered
     unsigned total_pixels;  // tile_cols * tile_rows * 64
