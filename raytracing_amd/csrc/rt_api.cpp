@@ -74,6 +74,7 @@ struct rt_context {
     int n_spheres = 0;   // spheres in the buffer (Scene::spheres().size())
     int sphere_cap = 0;  // allocated entries (multiple of RT_CHUNK)
 
+    int last_blocks = 0, last_threads = 0; // geometry of the last stream-kernel launch
     unsigned* d_work = nullptr;           // RT_WORK_BYTES: span counters + finished-workgroup count
     unsigned long long* d_rays = nullptr; // RT_RAY_BYTES: ray counters, summed by rt_get_counters
     uint64_t paths = 0;
@@ -201,14 +202,21 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     return RT_OK;
 }
 
-// Workgroup size and count of the persistent kernel: aim for 16 waves per CU, bounded by the
-// LDS one workgroup needs (geometry + per-wave candidate masks).
+// Workgroup size and count of the persistent kernel.  The kernel is bound by VALU issue, which
+// two waves per SIMD already saturate; more waves only add start-up and drain cost (every wave
+// ends with a few half-empty iterations).  Measured on MI355X: 12 waves per CU is the best or
+// within noise of it from 2 to 16 frames per dispatch, 8 when a dispatch gives a wave fewer than
+// 16 lane-fills of paths (one 1080p frame).  Bounded by the LDS one workgroup needs (geometry +
+// per-wave candidate masks).
 void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* threads)
 {
     int t = c->threads > 0 ? c->threads : (P.n_lds <= 1024 ? 256 : 1024);
     t = std::max(64, std::min(1024, t / 64 * 64));
     const size_t lds = rt_stream_lds_bytes(P.n_lds, t);
-    int per_cu = std::min<int>(16 / (t / 64), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
+    const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
+    int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)c->cu_count ? 8 : 12;
+    if (t == 1024) waves_per_cu = 16;  // whole workgroups: one per CU
+    int per_cu = std::min<int>(std::max(1, waves_per_cu / (t / 64)), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
     per_cu = std::max(1, per_cu);
     int b = c->blocks > 0 ? c->blocks : c->cu_count * per_cu;
     const unsigned lanes_needed = (P.total_pixels + (unsigned)t - 1) / (unsigned)t;
@@ -239,6 +247,8 @@ int launch(rt_context* c, const RtParams& P, bool record)
     const bool sgeom = c->kernel == RT_KERNEL_STREAM_SGPR ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES);
     HIP_TRY(rt_launch_stream(P, fused, record, sgeom, blocks, threads, c->stream));
+    c->last_blocks = blocks;
+    c->last_threads = threads;
     return RT_OK;
 }
 
@@ -470,9 +480,10 @@ int rt_get_info(rt_context* c, int* device, int* cu_count, int* blocks, int* thr
     if (!c) return fail(RT_E_INVALID, "ctx is null");
     if (device) *device = c->device;
     if (cu_count) *cu_count = c->cu_count;
-    int b = c->blocks, t = c->threads;
+    // the geometry of the last stream launch, or what a one-frame dispatch would use
+    int b = c->last_blocks, t = c->last_threads;
     RtParams P;
-    if (c->have_ubo && make_params(c, 1, &P) == RT_OK) stream_geometry(c, P, &b, &t);
+    if (b == 0 && c->have_ubo && make_params(c, 1, &P) == RT_OK) stream_geometry(c, P, &b, &t);
     if (blocks) *blocks = b;
     if (threads) *threads = t;
     return RT_OK;
