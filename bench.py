@@ -83,8 +83,25 @@ def cpu_baseline(scene, profile, max_depth, seconds):
         "cores": cores,
         "kind": "port",
         "sample": f"{frames} whole frame(s) of the same {WIDTH}x{HEIGHT} scene, depth {max_depth}, "
-                  f"{rays} rays in {dt:.1f} s (CPU oracle, {'fused' if profile else 'strict'} profile)",
+                  f"{rays} rays in {dt:.1f} s (CPU oracle, {'fused' if profile else 'strict'} profile); "
+                  + lavapipe_probe(),
     }
+
+
+def lavapipe_probe():
+    """The baseline of choice would be the reference shader on Mesa lavapipe (CPU Vulkan).  That
+    needs a Vulkan loader, the lvp ICD and a GLSL compiler on this machine; say what is there."""
+    import ctypes.util
+    import glob
+    import shutil
+
+    loader = ctypes.util.find_library("vulkan")
+    icd = glob.glob("/usr/share/vulkan/icd.d/lvp_icd*.json") + glob.glob("/etc/vulkan/icd.d/lvp_icd*.json")
+    glslc = shutil.which("glslc") or shutil.which("glslangValidator")
+    if loader and icd and glslc:
+        return "lavapipe present but no Vulkan host harness is part of this build"
+    missing = [n for n, ok in (("libvulkan", loader), ("lvp ICD", icd), ("glslc/glslangValidator", glslc)) if not ok]
+    return "lavapipe baseline not possible here: " + ", ".join(missing) + " not found"
 
 
 def interactive(args, rank, world, device, backend):

@@ -451,3 +451,45 @@ def test_default_scene_1080p_1024_frames(rt, default_scene):
     mse = np.mean((a - b) ** 2)
     psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
     assert psnr >= 50.0, psnr
+
+
+def test_ties_and_degenerate_spheres(rt, default_scene):
+    """Exact duplicates (the shader's strict `<` keeps the lowest index, and only indices 0-2 emit),
+    concentric spheres, radius 0, a negative radius, a sphere around the camera, very large and very
+    small spheres, and non-finite entries: every one goes through the literal expressions."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, 96, 17)
+    sph = scene.spheres
+    cam = scene.camera["camera_position"][0]
+    sph[40] = sph[1]                      # duplicate of an emitter at a non-emitting index
+    sph[2] = sph[41]                      # an emitting index duplicating a later sphere
+    sph[50]["center"] = sph[51]["center"]
+    sph[50]["radius"] = sph[51]["radius"] * 0.5    # concentric, inside
+    sph[52]["radius"] = 0.0
+    sph[53]["radius"] = -sph[53]["radius"]
+    sph[54]["center"] = cam
+    sph[54]["radius"] = 80.0              # the camera sits inside this one
+    sph[55]["center"] = (0.0, -1.0e6, 0.0)
+    sph[55]["radius"] = 1.0e6 - 20.0      # a ground plane as a huge sphere
+    sph[56]["radius"] = 1.0e-6
+    sph[57]["center"] = (np.inf, 0.0, 0.0)
+    sph[58]["center"] = (np.nan, 0.0, 0.0)
+    sph[59]["radius"] = np.inf
+    sph[60]["radius"] = np.nan
+    sph[61]["color"] = (np.nan, 0.5, 0.5)
+    for count in (96, 54):                # with and without the enclosing / huge / non-finite ones
+        for profile in (0, 1):
+            for kernel in (0, 1, 3):
+                acc, col, cnt = _render_gpu(rt, scene, 160, 96, profile=profile, kernel=kernel, n_frames=3, depth=12,
+                                            sphere_count=count)
+                cacc, ccol, crays = _render_cpu(scene, 160, 96, profile=profile, n_frames=3, depth=12,
+                                                sphere_count=count)
+                assert np.array_equal(_bits(acc), _bits(cacc)), (count, profile, kernel)
+                assert np.array_equal(col, ccol), (count, profile, kernel)
+                assert cnt["rays"] == crays
+    ubo = scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    ubo["sphereCount"][0] = 54
+    crec, _ = O.trace_crop(ubo, sph, 160, 96, 0, 0, 160, 96, max_depth=12)
+    hits = crec["hit"][crec["hit"] >= 0]
+    assert 1 in hits and 40 not in hits          # the duplicate never wins a tie
+    assert 52 not in hits                         # radius 0 is never hit
