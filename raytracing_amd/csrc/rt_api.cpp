@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -337,6 +338,8 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     const int cap = std::max(RT_CHUNK, (count + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK);
     HIP_TRY(hipStreamSynchronize(c->stream));  // no launch may still read the old buffers
     if (cap > c->sphere_cap) {
+        c->n_spheres = 0;  // until the new buffers are filled there is nothing to trace
+        c->have_materials = false;
         if (c->d_spheres) HIP_TRY(hipFree(c->d_spheres));
         if (c->d_geom) HIP_TRY(hipFree(c->d_geom));
         if (c->d_radius) HIP_TRY(hipFree(c->d_radius));
@@ -353,10 +356,17 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     // (2k, 2k+1)   float4 {cx0, cx1, cy0, cy1}, float4 {cz0, cz1, w0, w1},
     // w = r*r - c.c + margin*(c.c + r*r), evaluated in double and rounded UP to float so the
     // margin is never eroded (see sieve_chunk in rt_kernels.hip).
-    std::vector<RtSphereAos> host(cap);
+    std::vector<RtSphereAos> host;
+    std::vector<float> geom, radius;
+    try {
+        host.resize(cap);
+        geom.resize((size_t)cap * 4);
+        radius.resize((size_t)cap);
+    } catch (const std::bad_alloc&) {
+        return fail(RT_E_NOMEM, "out of host memory staging %d spheres", count);
+    }
     memset(host.data(), 0, host.size() * sizeof(RtSphereAos));
     if (count) memcpy(host.data(), aos, (size_t)count * sizeof(RtSphereAos));
-    std::vector<float> geom((size_t)cap * 4), radius((size_t)cap);
     for (int i = 0; i < cap; i++) {
         const RtSphereAos& s = host[i];
         const size_t base = (size_t)(i >> 1) * 8 + (i & 1);
@@ -592,7 +602,15 @@ int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_
     P.rec_h = h;
     const size_t npix = (size_t)n_frames * w * h;
     const size_t nrec = npix * (size_t)c->max_depth;
-    std::vector<rt_record> init(nrec);
+    if (nrec > ((size_t)1 << 27))  // 2 GiB of records: a crop is a test probe, not an image
+        return fail(RT_E_INVALID, "crop of %d frames x %dx%d x depth %d holds too many records", n_frames, w, h,
+                    c->max_depth);
+    std::vector<rt_record> init;
+    try {
+        init.resize(nrec);
+    } catch (const std::bad_alloc&) {
+        return fail(RT_E_NOMEM, "out of host memory for %zu records", nrec);
+    }
     for (auto& r : init) {
         r.hit = -2;
         r.hash[0] = r.hash[1] = r.hash[2] = 0;
@@ -602,7 +620,8 @@ int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_
     HIP_TRY(hipMalloc(&d_rec, nrec * sizeof(rt_record)));
     hipError_t e = hipMemcpy(d_rec, init.data(), nrec * sizeof(rt_record), hipMemcpyHostToDevice);
     if (e == hipSuccess && light) e = hipMalloc(&d_light, npix * 3 * sizeof(float));
-    if (e == hipSuccess && light) e = hipMemset(d_light, 0, npix * 3 * sizeof(float));
+    // on the context's stream: it does not wait for work queued on the default stream
+    if (e == hipSuccess && light) e = hipMemsetAsync(d_light, 0, npix * 3 * sizeof(float), c->stream);
     if (e != hipSuccess) {
         (void)hipFree(d_rec);
         if (d_light) (void)hipFree(d_light);
@@ -704,7 +723,7 @@ int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t 
     unsigned long long* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 6 * sizeof(float)));
     hipError_t e = hipMalloc(&d_out, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(d_out, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = rt_launch_sieve_audit(P, d_rays, n_rays, d_out, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
