@@ -290,6 +290,8 @@ def main():
             "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
             "roofline": {
                 "bound": "valu",
+                "bound_detail": "FP32 vector ALU: the path has no matrix contraction, so neither HBM nor MFMA bounds it; "
+                                "the FP32 vector peak equals the dense FP32 MFMA peak (157.3 TFLOP/s)",
                 "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",

@@ -385,7 +385,7 @@ def test_errors_are_reported(rt, default_scene):
 # ---------------------------------------------------------------- full-size properties
 
 def test_full_size_4k_stream_equals_tile(rt, rtiow_scene):
-    """BASELINE size (3840x2160, ~500 spheres): too big for the oracle in seconds, so check the
+    """Headline size (3840x2160, ~500 spheres): too big for the oracle in seconds, so check the
     two independently written kernels against each other over the whole image, the ray
     counter, and the oracle on a strided sample of tiles."""
     w, h = 3840, 2160
