@@ -47,6 +47,21 @@ void ComputePipeline::updateScene()
         check(rt_upload_spheres(m_ctx, s.data(), (int)s.size()));
         m_uploaded = s;
         m_haveUpload = true;
+        m_uploadedMaterials.clear();  // a sphere upload drops the device's materials
+    }
+    // material extension: parallel to the spheres, uploaded when it says anything and has changed
+    m_scene.syncMaterials();
+    const std::vector<Material>& m = m_scene.m_materials;
+    bool any = false;
+    for (const Material& x : m) any = any || x.kind != 0.f;
+    const bool sameMaterials = m.size() == m_uploadedMaterials.size() &&
+                               (m.empty() || std::memcmp(m.data(), m_uploadedMaterials.data(), m.size() * sizeof(Material)) == 0);
+    if (any && !sameMaterials) {
+        check(rt_upload_materials(m_ctx, &m[0].kind, (int)m.size()));
+        m_uploadedMaterials = m;
+    } else if (!any && !m_uploadedMaterials.empty()) {
+        check(rt_upload_materials(m_ctx, nullptr, 0));
+        m_uploadedMaterials.clear();
     }
     check(rt_set_uniforms(m_ctx, &m_scene.camera()));
 }

@@ -42,6 +42,7 @@ class ComputePipeline {
     rt_context* m_ctx = nullptr;
     uint32_t m_width, m_height;
     std::vector<Sphere> m_uploaded;  // what the device holds
+    std::vector<Material> m_uploadedMaterials;  // empty: the device has no materials
     bool m_haveUpload = false;
 };
 

@@ -93,3 +93,26 @@ def test_headless_reports_errors_like_the_reference(tmp_path):
     env = dict(os.environ, RT_SCENE=str(tmp_path / "missing.yaml"))
     res = subprocess.run([BINARY, "--frames", "1"], env=env, capture_output=True, text=True, timeout=60)
     assert res.returncode == 1 and "cannot open scene file" in res.stdout
+
+
+def test_headless_renders_a_scene_file_with_materials(tmp_path):
+    """The C++ host uploads the optional per-sphere materials of a scene file (4th sphere element):
+    8 still frames of the RTIOW layout with materials equal the oracle's."""
+    scene = rt.Scene.generate(rt.KIND_RTIOW_MATERIALS, 0, 5)
+    path = tmp_path / "materials.yaml"
+    scene.save(str(path))
+    out = tmp_path / "out.ppm"
+    res = subprocess.run([BINARY, "--size", "192x112", "--frames", "8", "--scene", str(path), "--out", str(out)],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    loaded = rt.Scene.load(str(path))
+    ubo = loaded.camera.copy()
+    # Application::Application installs the launch orientation (src/application.cpp:10-23)
+    f, r, u = O.camera_basis(90.0, 0.0)
+    ubo["camera_forward"][0], ubo["camera_right"][0], ubo["camera_up"][0] = f, r, u
+    ubo["frameCount"][0] = 1
+    _, color, _ = O.render(ubo, loaded.spheres, 192, 112, n_frames=8, materials=loaded.materials, threads=8)
+    plain = O.render(ubo, loaded.spheres, 192, 112, n_frames=8, threads=8)[1]
+    got = _read_ppm(out)
+    assert np.array_equal(got, color[..., :3])
+    assert not np.array_equal(got, plain[..., :3])
