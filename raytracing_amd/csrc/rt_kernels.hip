@@ -309,16 +309,20 @@ __device__ __forceinline__ bool path_bounce(Path& p, const RtParams& P, int idx,
 
 // shader.comp:44-60 for one sphere, literally.  The square root and the divide are skipped when
 // b >= 0: then -b - sqrt(disc) <= 0, so t > 0 is false whatever the root is -- same outcome.
+// far_root (material extension, dielectric spheres only): when the near root is not positive the
+// far one is taken, so a ray that was refracted into the sphere meets its far wall.
 template <bool FUSED>
 __device__ __forceinline__ void test_sphere(const Path& p, float a, float cx, float cy, float cz,
-                                            float r, int i, float& best, int& idx)
+                                            float r, int i, float& best, int& idx, bool far_root = false)
 {
     const float ocx = p.ox - cx, ocy = p.oy - cy, ocz = p.oz - cz;
     const float b = 2.0f * dot3<FUSED>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
     const float c = mad<FUSED>(-r, r, dot3<FUSED>(ocx, ocy, ocz, ocx, ocy, ocz));  // dot(oc,oc) - r*r
     const float disc = mad<FUSED>(b, b, -((4.0f * a) * c));
-    if (!(disc < 0.0f) && b < 0.0f) {
-        const float t = (-b - sqrtf(disc)) / (2.0f * a);
+    if (!(disc < 0.0f) && (b < 0.0f || far_root)) {
+        const float sq = sqrtf(disc);
+        float t = (-b - sq) / (2.0f * a);
+        if (far_root && !(t > 0.0f)) t = (-b + sq) / (2.0f * a);
         if (t > 0.0f && t < best) {
             best = t;
             idx = i;
@@ -404,7 +408,8 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
             int idx = -1;
             for (int i = 0; i < P.sphere_count; i++) {
                 const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
-                test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx);
+                const bool far_root = P.materials != nullptr && P.materials[i].x == 3.0f;
+                test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
             }
             if (alive) {
                 nrays++;
@@ -698,12 +703,14 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                         const int b = __clz(cur);
                         cur &= ~(0x80000000u >> b);
                         const int i = curbase + b;
+                        bool far_root = false;
+                        if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;  // wave-uniform branch
                         if (P.n_lds) {
                             const float* f = gf + (i >> 1) * 8 + (i & 1);
-                            test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx);
+                            test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx, far_root);
                         } else {
                             const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
-                            test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx);
+                            test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
                         }
                     }
                 }

@@ -100,6 +100,39 @@ def test_scene_yaml_carries_materials_only_when_present(tmp_path):
             rt.Scene.parse(good.replace(first, bad, 1))
 
 
+def test_glass_sphere_is_entered_and_left():
+    """A dielectric sphere is also hit from inside (far root), so a ray refracts in, crosses it and
+    refracts out: seen head-on, most paths are [glass, glass, sky]."""
+    import raytracing_amd as rt
+
+    scene = rt.Scene.generate(rt.KIND_CUBE, 4, 1)
+    sph = scene.spheres
+    cam = scene.camera["camera_position"][0]
+    fwd = scene.camera["camera_forward"][0]
+    for i in range(3):  # the three emitters, out of sight behind the camera
+        sph[i]["center"] = cam - fwd * 1000.0 + np.float32(i * 50)
+        sph[i]["radius"] = 1.0
+    sph[3]["center"] = cam + fwd * 10.0
+    sph[3]["radius"] = 2.0
+    sph[3]["color"] = (1.0, 1.0, 1.0)
+    mats = np.zeros((4, 2), np.float32)
+    mats[3] = (3.0, 1.5)
+    ubo = scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    for profile in (O.STRICT, O.FUSED):
+        rec, light = O.trace_crop(ubo, sph, 256, 144, 112, 56, 32, 32, max_depth=8, profile=profile, materials=mats)
+        hit = rec["hit"][0].reshape(-1, 8)
+        through = np.all(hit[:, :3] == (3, 3, -1), axis=1)
+        assert through.mean() > 0.85
+        assert np.all(hit[:, 0] == 3)
+        # without the material the near-mirror reflects every one of them straight back to the sky
+        rec0, _ = O.trace_crop(ubo, sph, 256, 144, 112, 56, 32, 32, max_depth=8, profile=profile)
+        assert np.all(rec0["hit"][0].reshape(-1, 8)[:, :2] == (3, -1))
+        # white glass loses nothing: the sky seen through it keeps the full first-bounce weight
+        sky = np.array([0.6, 0.7, 0.9], np.float32) * np.float32(0.15)
+        np.testing.assert_allclose(light[0].reshape(-1, 3)[through], np.tile(sky, (through.sum(), 1)), rtol=1e-6)
+
+
 # ---------------------------------------------------------------- GPU: kernels vs the restatement
 
 @pytest.mark.gpu
