@@ -11,19 +11,20 @@
 // Two kernels, same results:
 //   rt_tile_kernel   one wave per 8x8 tile, one lane per pixel, the sphere loop exactly as
 //                    the shader writes it.  The plain mapping, kept as the in-GPU cross-check.
-//   rt_stream_kernel persistent waves.  A lane whose path (or pixel) has ended takes the next
-//                    pixel from a shared counter, so all 64 lanes carry a live ray in almost
-//                    every pass over the spheres, whatever the spread of bounce counts.  The
-//                    sphere loop is split in two:
-//                      sieve: for 32 spheres at a time, packed-f32 math on sphere PAIRS computes
-//                             q = s*s - a*c (disc = 4q) and shifts its sign bit into a per-lane
-//                             mask: 6 packed ops + 1 shift per ray-sphere test, no branch;
-//                      walk : each lane then visits only its own candidates (q >= 0) in index
-//                             order and evaluates the shader's expressions literally
-//                             (sqrt, divide, t > 0, t < best), so ties and rounding are the
-//                             shader's.
-//                    Geometry is staged once per workgroup in LDS as pair-packed float4s and read
-//                    with wave-uniform (broadcast) ds_read_b128.
+//   rt_stream_kernel persistent waves.  A lane whose pixel is finished takes the next pixel
+//                    from its wave's span (64-pixel spans drawn from per-XCD work queues), so all
+//                    64 lanes carry a live ray in almost every pass over the spheres, whatever
+//                    the spread of bounce counts.  The sphere loop is split in two:
+//                      sieve: for 32 spheres at a time, packed-f32 math on sphere PAIRS evaluates
+//                             a conservative form of the discriminant's sign and shifts it into a
+//                             per-lane mask: 8 packed ops + 2 shifts per pair = 5 instructions
+//                             per ray-sphere test, no branch (see sieve_pair);
+//                      walk : each lane then visits only its own candidates in index order and
+//                             evaluates the shader's expressions literally (sqrt, divide, t > 0,
+//                             t < best), so ties and rounding are the shader's.
+//                    The sieve reads pair-packed geometry through the scalar cache (SGPR
+//                    operands) or, for large scenes, from a copy staged once per workgroup in
+//                    LDS with wave-uniform ds_read_b128; the walk reads the LDS copy.
 #include <hip/hip_runtime.h>
 
 #include "rt_params.h"

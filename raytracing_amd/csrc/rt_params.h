@@ -23,7 +23,7 @@ constexpr int RT_MAX_LDS_SPHERES = 4096;
 constexpr int RT_MAX_SGPR_SPHERES = 2048;
 // Relative safety margin of the sieve (2^-16 = 256 ulp): see sieve_chunk in rt_kernels.hip.
 constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
-// Pixels a wave takes from the shared work counter at a time.
+// Pixels a wave takes from a work queue at a time (one 8x8 tile).
 #ifndef RT_SPAN_PIXELS
 #define RT_SPAN_PIXELS 64
 #endif
@@ -73,7 +73,7 @@ struct RtParams {
     const float2* materials;     // material extension: {kind, param} per sphere; null = all kind 0
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
-    unsigned* work_counter;      // zeroed before every stream-kernel launch
+    unsigned* work_counter;      // RT_WORK_BYTES block of queue counters; all zero between launches
     unsigned long long* rays;    // += Trace() calls
     rt_record* records;          // record mode only
     float* rec_light;            // record mode only (may be null)
