@@ -18,7 +18,10 @@ struct RtSphereAos {
 constexpr int RT_CHUNK = 32;
 constexpr int RT_SG_CHUNKS = 16;
 // Largest sphere count whose geometry stream is staged in LDS (16 B per sphere).
-constexpr int RT_MAX_LDS_SPHERES = 4096;
+#ifndef RT_MAX_LDS
+#define RT_MAX_LDS 4096
+#endif
+constexpr int RT_MAX_LDS_SPHERES = RT_MAX_LDS;
 // Up to this many spheres RT_KERNEL_STREAM reads the sieve geometry through the scalar cache.
 constexpr int RT_MAX_SGPR_SPHERES = 2048;
 // Relative safety margin of the sieve (2^-16 = 256 ulp): see sieve_chunk in rt_kernels.hip.

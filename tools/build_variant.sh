@@ -8,7 +8,10 @@ name=$1; shift
 mkdir -p ../../variants build
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. \
     --offload-arch=gfx950 "$@" -c rt_kernels.hip -o ../../variants/rt_kernels_$name.o
-objs=$(ls build/*.o | grep -v rt_kernels.o)
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/lib$name.so ../../variants/rt_kernels_$name.o $objs
-rm ../../variants/rt_kernels_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. \
+    "$@" -c rt_api.cpp -o ../../variants/rt_api_$name.o
+objs=$(ls build/*.o | grep -v "rt_kernels.o\|rt_api.o")
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/lib$name.so ../../variants/rt_kernels_$name.o \
+    ../../variants/rt_api_$name.o $objs
+rm ../../variants/rt_kernels_$name.o ../../variants/rt_api_$name.o
 echo variants/lib$name.so
