@@ -39,7 +39,9 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--frames-per-step", type=int, default=8)
     p.add_argument("--profile", choices=["strict", "fused"], default="strict")
-    p.add_argument("--kernel", choices=["stream", "tile"], default="stream")
+    p.add_argument("--kernel", choices=["stream", "tile", "culled"], default="stream",
+                   help="stream: the brute-force kernel the metric is quoted on; culled: the same kernel over a "
+                        "spatially sorted sphere list, skipping groups no ray of a wave can touch (same image)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--max-depth", type=int, default=50)
     p.add_argument("--workload", choices=["rtiow4k", "interactive"], default="rtiow4k",
@@ -199,7 +201,7 @@ def main():
 
     scene = rt.Scene.generate(rt.KIND_RTIOW_MATERIALS if args.materials else rt.KIND_RTIOW, 0, SCENE_SEED)
     profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
-    kernel = rt.KERNEL_TILE if args.kernel == "tile" else rt.KERNEL_STREAM
+    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED}.get(args.kernel, rt.KERNEL_STREAM)
     fps = args.frames_per_step
 
     split = SampleSplit(rank, world)

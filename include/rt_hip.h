@@ -51,7 +51,12 @@ enum {
                              picks one of the two geometry sources below by sphere count      */
     RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
     RT_KERNEL_STREAM_SGPR = 2, /* STREAM, sieve geometry read through the scalar cache (SGPRs) */
-    RT_KERNEL_STREAM_LDS = 3   /* STREAM, sieve geometry read from the LDS copy                */
+    RT_KERNEL_STREAM_LDS = 3,  /* STREAM, sieve geometry read from the LDS copy                */
+    RT_KERNEL_STREAM_CULLED = 4 /* STREAM over a spatially sorted copy of the sphere list: groups of 8
+                                  spheres whose bounding sphere no ray of the wave can touch are
+                                  skipped.  Not brute force any more (the step the reference's
+                                  readme.md:38 names, a spatial hierarchy); same bits.  Scenes of more
+                                  than 4096 traced spheres fall back to RT_KERNEL_STREAM.           */
 };
 
 /* When the accumulation texel is zeroed. */
@@ -194,6 +199,13 @@ int rt_debug_math(rt_context* ctx, int op, const float* a, const float* b, const
    0); out[2]: spheres with a non-negative STRICT discriminant; out[3]: spheres the sieve
    passed.  No reference counterpart. */
 int rt_debug_sieve_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[4]);
+
+/* Test hook for RT_KERNEL_STREAM_CULLED: runs its group-culling test on n_rays caller-supplied
+   rays against the bounding spheres of the sorted sphere groups.  out[0]: (ray, sphere) pairs
+   whose group was culled although the sphere's literal discriminant (either float profile) was
+   not negative -- must be 0; out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs
+   tested.  No reference counterpart. */
+int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[3]);
 
 const char* rt_last_error(void);
 

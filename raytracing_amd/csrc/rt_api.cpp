@@ -17,8 +17,10 @@
 
 // launchers defined in rt_kernels.hip
 size_t rt_stream_lds_bytes(int n_pad, int threads);
-hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, bool sgeom, int blocks, int threads,
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st);
+hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
+                                hipStream_t st);
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
 hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
                              int y1, float divisor, hipStream_t st);
@@ -74,6 +76,15 @@ struct rt_context {
     bool have_materials = false;    // true when some sphere has a kind other than 0
     int n_spheres = 0;   // spheres in the buffer (Scene::spheres().size())
     int sphere_cap = 0;  // allocated entries (multiple of RT_CHUNK)
+
+    // RT_KERNEL_STREAM_CULLED: the first `cull_count` spheres sorted in space (built on demand)
+    std::vector<RtSphereAos> h_spheres;  // host copy of the upload, the source of the sorted copy
+    float4* d_cgeom = nullptr;    // pair-packed sieve geometry of the sorted list
+    float* d_cradius = nullptr;   // radii of the sorted list
+    float4* d_bounds = nullptr;   // pair-packed bounding spheres of the groups of RT_CULL_GROUP slots
+    int* d_perm = nullptr;        // sorted slot -> index in d_spheres
+    int cull_cap = 0;             // slots allocated
+    int cull_count = -1;          // sphere_count the sorted copy was built for; -1 = none / stale
 
     int last_blocks = 0, last_threads = 0; // geometry of the last stream-kernel launch
     unsigned* d_work = nullptr;           // RT_WORK_BYTES: span counters + finished-workgroup count
@@ -203,6 +214,157 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     return RT_OK;
 }
 
+// w of the sieve geometry: r*r - c.c + margin*(c.c + r*r), evaluated in double and rounded UP to
+// float so the margin is never eroded (see sieve_pair in rt_kernels.hip).
+float sieve_w(double cx, double cy, double cz, double r)
+{
+    const double cc = cx * cx + cy * cy + cz * cz;
+    const double rr = r * r;
+    const double w = rr - cc + (double)RT_SIEVE_MARGIN * (cc + rr);
+    float wf = (float)w;
+    if ((double)wf < w) wf = std::nextafter(wf, INFINITY);
+    return wf;
+}
+
+uint32_t morton10(uint32_t v)  // spread the low 10 bits of v three apart
+{
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// The sorted copy of the first `count` spheres for RT_KERNEL_STREAM_CULLED.
+//
+// Order: spheres much larger than the typical one (and any with a non-finite entry) first, the
+// rest along a Morton curve through their centres, so that every group of RT_CULL_GROUP
+// consecutive slots is compact.  Each group gets a bounding sphere (c_b, R_b); the kernel skips a
+// group when its sieve, run on the bounding sphere with the margin RT_CULL_MARGIN_O on o.o,
+// rejects it for every ray of the wave.
+//
+// Why a skipped group cannot hold a hit (u = 2^-24, first order in u; notation of sieve_pair):
+// the computed g of any sphere (c, r) satisfies |g - (F + m)| <= err, F = r^2 - D^2, D the
+// distance from c to the ray's line up to 4u|c-o|^2, m = 2^-16 (o.o + c.c + r^2), err <= 62u(o.o +
+// c.c) + 7u r^2.  A sphere i of the group is certainly rejected by its own sieve (and therefore,
+// the sieve being conservative, cannot be hit by the shader's test) once
+//     dist_i >= r_i + kappa (|o| + |c_i| + r_i),   kappa = sqrt(326 u) = 0.004408,
+// because then dist_i^2 >= r_i^2 + m_i + err_i + 4u|c_i-o|^2.  With rho_i = |c_i - c_b| and
+//     A = max_i ( rho_i + r_i + kappa (|c_i| + r_i) ),        R_b = A sqrt(1 + 2^-6) (rounded up),
+// dist_i >= dist_b - rho_i makes dist_b >= A + kappa|o| sufficient, and since 2 A kappa |o| <=
+// 2^-6 A^2 + 64 kappa^2 |o|^2 that follows from dist_b^2 >= R_b^2 + 65 * 326u |o|^2 = R_b^2 + 21190u
+// |o|^2.  The group test being negative means dist_b^2 > R_b^2 + m_b - err_b - 4u|c_b-o|^2 >= R_b^2 +
+// (2^-9 - 70u)|o|^2 = R_b^2 + 32698u |o|^2.  Hence RT_CULL_MARGIN_O = 2^-9.
+struct CulledScene {
+    std::vector<float> geom;    // 4 floats per slot, pair-packed
+    std::vector<float> radius;  // per slot
+    std::vector<float> bounds;  // 4 floats per group, pair-packed, padded to 64 groups
+    std::vector<int> perm;      // per slot
+};
+
+void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, CulledScene* out)
+{
+    const double kKappa = 0.00441;  // >= sqrt(326 * 2^-24)
+    const float inf = INFINITY;
+    auto finite = [](const RtSphereAos& s) {
+        return std::isfinite(s.cx) && std::isfinite(s.cy) && std::isfinite(s.cz) && std::isfinite(s.radius);
+    };
+    // typical radius = median of the finite ones
+    std::vector<float> radii;
+    for (int i = 0; i < count; i++)
+        if (finite(src[i])) radii.push_back(std::fabs(src[i].radius));
+    float median = 0.f;
+    if (!radii.empty()) {
+        std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+        median = radii[radii.size() / 2];
+    }
+    std::vector<char> big(count, 0);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < count; i++) {
+        const RtSphereAos& s = src[i];
+        big[i] = !finite(s) || std::fabs(s.radius) > 4.0f * median;
+        if (big[i]) continue;
+        const double c[3] = {s.cx, s.cy, s.cz};
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], c[k]);
+            hi[k] = std::max(hi[k], c[k]);
+        }
+    }
+    std::vector<std::pair<uint32_t, int>> keyed(count);
+    for (int i = 0; i < count; i++) {
+        uint32_t key = 0;
+        if (!big[i]) {
+            const double c[3] = {src[i].cx, src[i].cy, src[i].cz};
+            uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                const double span = hi[k] - lo[k];
+                const double t = span > 0 ? (c[k] - lo[k]) / span : 0.0;
+                q[k] = (uint32_t)std::min(1023.0, std::max(0.0, t * 1023.0));
+            }
+            key = 1u + (morton10(q[0]) | (morton10(q[1]) << 1) | (morton10(q[2]) << 2));
+        }
+        keyed[i] = {key, i};
+    }
+    std::sort(keyed.begin(), keyed.end());  // ties by index: the order is a function of the scene alone
+
+    const int ngroups = n_pad / RT_CULL_GROUP;
+    const int nbounds = (ngroups + 63) / 64 * 64;
+    out->geom.assign((size_t)n_pad * 4, 0.f);
+    out->radius.assign((size_t)n_pad, 0.f);
+    out->perm.assign((size_t)n_pad, 0);
+    out->bounds.assign((size_t)nbounds * 4, 0.f);
+    auto put = [](std::vector<float>& v, int slot, float x, float y, float z, float w) {
+        const size_t base = (size_t)(slot >> 1) * 8 + (slot & 1);
+        v[base + 0] = x; v[base + 2] = y; v[base + 4] = z; v[base + 6] = w;
+    };
+    for (int k = 0; k < n_pad; k++) {
+        if (k < count) {
+            const RtSphereAos& s = src[keyed[k].second];
+            put(out->geom, k, s.cx, s.cy, s.cz, sieve_w(s.cx, s.cy, s.cz, s.radius));
+            out->radius[k] = s.radius;
+            out->perm[k] = keyed[k].second;
+        } else {
+            put(out->geom, k, 0.f, 0.f, 0.f, -inf);  // padding: rejected whatever the ray
+        }
+    }
+    for (int g = 0; g < nbounds; g++) {
+        const int first = g * RT_CULL_GROUP, end = std::min(count, first + RT_CULL_GROUP);
+        if (first >= count) {
+            put(out->bounds, g, 0.f, 0.f, 0.f, -inf);  // no spheres: never needed
+            continue;
+        }
+        bool ok = true;
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        for (int k = first; k < end; k++) {
+            const RtSphereAos& s = src[keyed[k].second];
+            ok = ok && finite(s);
+            const double c[3] = {s.cx, s.cy, s.cz};
+            for (int a = 0; a < 3; a++) {
+                blo[a] = std::min(blo[a], c[a]);
+                bhi[a] = std::max(bhi[a], c[a]);
+            }
+        }
+        if (!ok) {
+            put(out->bounds, g, 0.f, 0.f, 0.f, inf);  // a non-finite member: always evaluated
+            continue;
+        }
+        // the centre as the float the kernel will see; everything else relative to that float
+        const float cb[3] = {(float)(0.5 * (blo[0] + bhi[0])), (float)(0.5 * (blo[1] + bhi[1])),
+                             (float)(0.5 * (blo[2] + bhi[2]))};
+        double A = 0.0;
+        for (int k = first; k < end; k++) {
+            const RtSphereAos& s = src[keyed[k].second];
+            const double dx = (double)s.cx - cb[0], dy = (double)s.cy - cb[1], dz = (double)s.cz - cb[2];
+            const double rho = std::sqrt(dx * dx + dy * dy + dz * dz);
+            const double r = std::fabs((double)s.radius);
+            const double cn = std::sqrt((double)s.cx * s.cx + (double)s.cy * s.cy + (double)s.cz * s.cz);
+            A = std::max(A, rho + r + kKappa * (cn + r));
+        }
+        const double Rb = A * std::sqrt(1.0 + 1.0 / 64.0) * (1.0 + 1e-9);
+        put(out->bounds, g, cb[0], cb[1], cb[2], sieve_w(cb[0], cb[1], cb[2], Rb));
+    }
+}
+
 // Workgroup size and count of the persistent kernel.  The kernel is bound by VALU issue, which
 // two waves per SIMD already saturate; more waves only add start-up and drain cost (every wave
 // ends with a few half-empty iterations).  Measured on MI355X: 12 waves per CU is the best or
@@ -226,8 +388,59 @@ void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* t
     *threads = t;
 }
 
-int launch(rt_context* c, const RtParams& P, bool record)
+// Build and upload the sorted copy of the first `count` spheres unless the device already holds it.
+int ensure_culled(rt_context* c, int count, int n_pad)
 {
+    if (c->cull_count == count) return RT_OK;
+    CulledScene cs;
+    try {
+        build_culled(c->h_spheres, count, n_pad, &cs);
+    } catch (const std::bad_alloc&) {
+        return fail(RT_E_NOMEM, "out of host memory sorting %d spheres", count);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // no launch may still read the old copy
+    c->cull_count = -1;
+    if (n_pad > c->cull_cap) {
+        if (c->d_cgeom) HIP_TRY(hipFree(c->d_cgeom));
+        if (c->d_cradius) HIP_TRY(hipFree(c->d_cradius));
+        if (c->d_bounds) HIP_TRY(hipFree(c->d_bounds));
+        if (c->d_perm) HIP_TRY(hipFree(c->d_perm));
+        c->d_cgeom = nullptr; c->d_cradius = nullptr; c->d_bounds = nullptr; c->d_perm = nullptr;
+        c->cull_cap = 0;
+        const size_t nbounds = ((size_t)n_pad / RT_CULL_GROUP + 63) / 64 * 64;
+        HIP_TRY(hipMalloc(&c->d_cgeom, (size_t)n_pad * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_cradius, (size_t)n_pad * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_bounds, nbounds * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_perm, (size_t)n_pad * sizeof(int)));
+        c->cull_cap = n_pad;
+    }
+    HIP_TRY(hipMemcpy(c->d_cgeom, cs.geom.data(), cs.geom.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_cradius, cs.radius.data(), cs.radius.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_bounds, cs.bounds.data(), cs.bounds.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_perm, cs.perm.data(), cs.perm.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->cull_count = count;
+    return RT_OK;
+}
+
+// The culled kernel's view of the scene: the sorted copies in place of geom/radius, plus bounds
+// and perm.  False when the scene does not qualify (empty, or too large to stage in LDS).
+int use_culled(rt_context* c, RtParams* P, bool* on)
+{
+    *on = false;
+    if (P->n_pad == 0 || P->n_pad > RT_MAX_LDS_SPHERES) return RT_OK;
+    int rc = ensure_culled(c, P->sphere_count, P->n_pad);
+    if (rc != RT_OK) return rc;
+    P->geom = c->d_cgeom;
+    P->radius = c->d_cradius;
+    P->bounds = c->d_bounds;
+    P->perm = c->d_perm;
+    *on = true;
+    return RT_OK;
+}
+
+int launch(rt_context* c, const RtParams& P_in, bool record)
+{
+    RtParams P = P_in;
     if (P.total_pixels == 0) return RT_OK;
     const bool fused = c->profile == RT_PROFILE_FUSED;
     const bool tile = c->kernel == RT_KERNEL_TILE;
@@ -245,9 +458,16 @@ int launch(rt_context* c, const RtParams& P, bool record)
     // d_work (span counters, workgroups finished) is zeroed at creation, and the kernel's last
     // workgroup zeroes it again on its way out, so no launch needs a memset in front of it.
     // The scalar cache serves the sieve faster than LDS while the geometry stream fits in it.
-    const bool sgeom = c->kernel == RT_KERNEL_STREAM_SGPR ||
-                       (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES);
-    HIP_TRY(rt_launch_stream(P, fused, record, sgeom, blocks, threads, c->stream));
+    int mode = c->kernel == RT_KERNEL_STREAM_SGPR || c->kernel == RT_KERNEL_STREAM_CULLED ||
+                       (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES)
+                   ? 1 : 0;
+    if (c->kernel == RT_KERNEL_STREAM_CULLED) {
+        bool on = false;
+        const int rc = use_culled(c, &P, &on);
+        if (rc != RT_OK) return rc;
+        if (on) mode = 2;
+    }
+    HIP_TRY(rt_launch_stream(P, fused, record, mode, blocks, threads, c->stream));
     c->last_blocks = blocks;
     c->last_threads = threads;
     return RT_OK;
@@ -310,6 +530,10 @@ int rt_destroy(rt_context* c)
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_radius) (void)hipFree(c->d_radius);
     if (c->d_materials) (void)hipFree(c->d_materials);
+    if (c->d_cgeom) (void)hipFree(c->d_cgeom);
+    if (c->d_cradius) (void)hipFree(c->d_cradius);
+    if (c->d_bounds) (void)hipFree(c->d_bounds);
+    if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -339,6 +563,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     HIP_TRY(hipStreamSynchronize(c->stream));  // no launch may still read the old buffers
     if (cap > c->sphere_cap) {
         c->n_spheres = 0;  // until the new buffers are filled there is nothing to trace
+        c->cull_count = -1;
         c->have_materials = false;
         if (c->d_spheres) HIP_TRY(hipFree(c->d_spheres));
         if (c->d_geom) HIP_TRY(hipFree(c->d_geom));
@@ -370,15 +595,10 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     for (int i = 0; i < cap; i++) {
         const RtSphereAos& s = host[i];
         const size_t base = (size_t)(i >> 1) * 8 + (i & 1);
-        const double cc = (double)s.cx * s.cx + (double)s.cy * s.cy + (double)s.cz * s.cz;
-        const double rr = (double)s.radius * s.radius;
-        const double w = rr - cc + (double)RT_SIEVE_MARGIN * (cc + rr);
-        float wf = (float)w;
-        if ((double)wf < w) wf = std::nextafter(wf, INFINITY);
         geom[base + 0] = s.cx;
         geom[base + 2] = s.cy;
         geom[base + 4] = s.cz;
-        geom[base + 6] = wf;
+        geom[base + 6] = sieve_w(s.cx, s.cy, s.cz, s.radius);
         radius[i] = s.radius;
     }
     HIP_TRY(hipMemcpy(c->d_spheres, host.data(), (size_t)cap * sizeof(RtSphereAos), hipMemcpyHostToDevice));
@@ -386,6 +606,9 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     HIP_TRY(hipMemcpy(c->d_radius, radius.data(), (size_t)cap * sizeof(float), hipMemcpyHostToDevice));
     c->n_spheres = count;
     c->have_materials = false;  // materials belong to a sphere list: upload them again
+    c->cull_count = -1;         // so does the sorted copy of the culled kernel
+    host.resize(count);
+    c->h_spheres.swap(host);
     return RT_OK;
 }
 
@@ -449,7 +672,7 @@ int rt_set_profile(rt_context* c, int profile)
 int rt_set_kernel(rt_context* c, int kernel)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_STREAM_LDS)
+    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_STREAM_CULLED)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
@@ -733,6 +956,35 @@ int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t 
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(RT_E_HIP, "sieve audit: %s", hipGetErrorString(e));
     for (int i = 0; i < 4; i++) out[i] = host[i];
+    return RT_OK;
+}
+
+// Audit of the culled kernel's group test (see rt_cull_audit_kernel).
+int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t out[3])
+{
+    if (!c || !rays || !out || n_rays <= 0) return fail(RT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    RtParams P;
+    int rc = make_params(c, 1, &P);
+    if (rc != RT_OK) return rc;
+    bool on = false;
+    rc = use_culled(c, &P, &on);
+    if (rc != RT_OK) return rc;
+    if (!on) return fail(RT_E_INVALID, "the culled kernel does not apply to this scene (%d spheres)", P.sphere_count);
+    float* d_rays = nullptr;
+    unsigned long long* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 6 * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt_launch_cull_audit(P, d_rays, n_rays, d_out, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    unsigned long long host[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(host, d_out, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RT_E_HIP, "cull audit: %s", hipGetErrorString(e));
+    for (int i = 0; i < 3; i++) out[i] = host[i];
     return RT_OK;
 }
 

@@ -312,9 +312,12 @@ __device__ __forceinline__ bool path_bounce(Path& p, const RtParams& P, int idx,
 // b >= 0: then -b - sqrt(disc) <= 0, so t > 0 is false whatever the root is -- same outcome.
 // far_root (material extension, dielectric spheres only): when the near root is not positive the
 // far one is taken, so a ray that was refracted into the sphere meets its far wall.
+// perm (culled kernel only): i and idx are slots of the sorted sphere list, visited in slot order;
+// the shader's strict `<` in index order keeps, among equal t, the lowest ORIGINAL index.
 template <bool FUSED>
 __device__ __forceinline__ void test_sphere(const Path& p, float a, float cx, float cy, float cz,
-                                            float r, int i, float& best, int& idx, bool far_root = false)
+                                            float r, int i, float& best, int& idx, bool far_root = false,
+                                            const int* perm = nullptr)
 {
     const float ocx = p.ox - cx, ocy = p.oy - cy, ocz = p.oz - cz;
     const float b = 2.0f * dot3<FUSED>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
@@ -324,7 +327,9 @@ __device__ __forceinline__ void test_sphere(const Path& p, float a, float cx, fl
         const float sq = sqrtf(disc);
         float t = (-b - sq) / (2.0f * a);
         if (far_root && !(t > 0.0f)) t = (-b + sq) / (2.0f * a);
-        if (t > 0.0f && t < best) {
+        bool closer = t < best;
+        if (perm != nullptr && t == best && idx >= 0) closer = perm[i] < perm[idx];
+        if (t > 0.0f && closer) {
             best = t;
             idx = i;
         }
@@ -439,14 +444,14 @@ struct SieveRay {
     v2f no2;               // -(o . o) * (1 - RT_SIEVE_MARGIN)
 };
 
-__device__ __forceinline__ SieveRay sieve_ray(const Path& p, float a, bool alive)
+__device__ __forceinline__ SieveRay sieve_ray(const Path& p, float a, bool alive, float margin = RT_SIEVE_MARGIN)
 {
     const float inv = __builtin_amdgcn_rsqf(a);  // 1 ulp is plenty: the margin absorbs it
     const float nx = p.dx * inv, ny = p.dy * inv, nz = p.dz * inv;
     const float d0 = __builtin_fmaf(nz, p.oz, __builtin_fmaf(ny, p.oy, nx * p.ox));
     const float o2 = __builtin_fmaf(p.oz, p.oz, __builtin_fmaf(p.oy, p.oy, p.ox * p.ox));
     // an idle lane gets -inf here, which makes every sphere's g = -inf: rejected
-    const float no2 = alive ? o2 * (RT_SIEVE_MARGIN - 1.0f) : -__builtin_inff();
+    const float no2 = alive ? o2 * (margin - 1.0f) : -__builtin_inff();
     SieveRay r;
     r.nnx = v2f{-nx, -nx}; r.nny = v2f{-ny, -ny}; r.nnz = v2f{-nz, -nz};
     r.d0 = v2f{d0, d0};
@@ -523,12 +528,36 @@ __device__ __forceinline__ uint32_t sieve_chunk_partial(GeomPtr g, const SieveRa
     return mask << (RT_CHUNK - 2 * RT_SIEVE_GROUP * ngroups);
 }
 
+// Culled kernel: a chunk of which only the groups of RT_CULL_GROUP spheres named in `need`
+// (bit 3 = first group) are evaluated; the spheres of the other groups come back as rejected.
+template <class GeomPtr>
+__device__ __forceinline__ uint32_t sieve_chunk_culled(GeomPtr g, const SieveRay& r, uint32_t need)
+{
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < RT_CHUNK / RT_CULL_GROUP; j++) {
+        if (need & (8u >> j)) {  // wave-uniform
+            v4f cur[RT_CULL_GROUP];
+#pragma unroll
+            for (int k = 0; k < RT_CULL_GROUP; k++) cur[k] = g[j * RT_CULL_GROUP + k];
+#pragma unroll
+            for (int k = 0; k < RT_CULL_GROUP / 2; k++) sieve_pair(mask, cur[2 * k], cur[2 * k + 1], r);
+        } else {
+            mask = (mask << RT_CULL_GROUP) | ((1u << RT_CULL_GROUP) - 1u);
+        }
+    }
+    return mask;
+}
+
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
 // n_pad*16 B sieve geometry + n_pad*4 B radii + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
 //
-// SGEOM selects where the sieve reads the geometry from: false = the LDS copy (wave-uniform
-// ds_read_b128), true = global memory through the scalar cache (s_load into SGPRs, which the
+// MODE selects where the sieve reads the geometry from: 0 = the LDS copy (wave-uniform
+// ds_read_b128), 1 = global memory through the scalar cache (s_load into SGPRs, which the
 // packed instructions take directly as their one scalar operand).  The walk reads LDS either way.
+// 2 = as 1, over the spatially sorted sphere list with group culling: per 512 spheres the wave
+// first sieves the 64 bounding spheres of their groups of 8, ORs the result over its lanes, and
+// skips the groups no lane can touch.
 typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
 #ifndef RT_GROUP_SGPR
 #define RT_GROUP_SGPR 2
@@ -537,9 +566,11 @@ typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
 #define RT_GROUP_LDS 4
 #endif
 
-template <bool FUSED, bool RECORD, bool SGEOM>
+template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
 {
+    constexpr bool SGEOM = MODE != 0;
+    constexpr bool CULL = MODE == 2;
     extern __shared__ float4 smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -666,13 +697,45 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
             for (int sg = 0; sg < nch; sg += RT_SG_CHUNKS) {
                 const int nsg = min(RT_SG_CHUNKS, nch - sg);
                 uint32_t summary = 0;
+                // culled kernel: bit (63 - n) of `wneed` = some lane's ray may touch group n of
+                // this supergroup (4 groups of 8 spheres per chunk)
+                unsigned long long wneed = ~0ull;
+                if constexpr (CULL) {
+                    const SieveRay srb = sieve_ray(p, a, alive, RT_CULL_MARGIN_O);
+                    ConstGeomPtr bnd = (ConstGeomPtr)(const void*)(P.bounds) + sg * (RT_CHUNK / RT_CULL_GROUP);
+                    uint32_t rej0, rej1 = 0xffffffffu;
+                    if (nsg == RT_SG_CHUNKS) {
+                        rej0 = sieve_chunk<RT_GROUP_SGPR>(bnd, srb);
+                        rej1 = sieve_chunk<RT_GROUP_SGPR>(bnd + RT_CHUNK, srb);
+                    } else {  // nsg chunks = nsg groups of 4 bounding spheres; the rest stay "rejected"
+                        const int n0 = min(nsg, 8), n1 = nsg - n0;
+                        rej0 = sieve_chunk_partial<2>(bnd, srb, n0) | (n0 < 8 ? 0xffffffffu >> (4 * n0) : 0u);
+                        if (n1 > 0) rej1 = sieve_chunk_partial<2>(bnd + RT_CHUNK, srb, n1) | (0xffffffffu >> (4 * n1));
+                    }
+                    uint32_t need0 = ~rej0, need1 = ~rej1;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        need0 |= (uint32_t)__shfl_xor((int)need0, off, 64);
+                        need1 |= (uint32_t)__shfl_xor((int)need1, off, 64);
+                    }
+                    wneed = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)need0) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)need1);
+                }
                 for (int c = 0; c < nsg; c++) {
                     constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
                     const bool last = sg + c == nch - 1;
                     constexpr int PGROUP = 2;  // the ragged last chunk goes 2 pairs at a time
                     const int ngroups = (P.last_chunk_count + 2 * PGROUP - 1) / (2 * PGROUP);
                     uint32_t rej;
-                    if constexpr (SGEOM) {
+                    if constexpr (CULL) {
+                        const uint32_t need = (uint32_t)(wneed >> (60 - 4 * c)) & 0xfu;
+                        if (need == 0u) {  // nobody's candidate: the walk never reads this chunk's masks
+                            summary <<= 1;
+                            continue;
+                        }
+                        ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
+                        rej = sieve_chunk_culled(g, sr, need);
+                    } else if constexpr (SGEOM) {
                         ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
                         rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
                                                                      : sieve_chunk<GROUP>(g, sr);
@@ -705,11 +768,13 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                         cur &= ~(0x80000000u >> b);
                         const int i = curbase + b;
                         bool far_root = false;
-                        if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;  // wave-uniform branch
+                        if (P.materials != nullptr)  // wave-uniform branch
+                            far_root = P.materials[CULL ? P.perm[i] : i].x == 3.0f;
                         if (P.n_lds) {
                             const float* f = gf + (i >> 1) * 8 + (i & 1);
-                            test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx, far_root);
-                        } else {
+                            test_sphere<FUSED>(p, a, f[0], f[2], f[4], radius[i], i, best, idx, far_root,
+                                               CULL ? P.perm : nullptr);
+                        } else {  // never the culled kernel: its scenes fit in LDS
                             const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
                             test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
                         }
@@ -717,6 +782,9 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                 }
             }
         }
+
+        if constexpr (CULL)
+            if (idx >= 0) idx = P.perm[idx];  // slot of the sorted list -> the shader's sphere index
 
         // ---- shade
         if (alive) {
@@ -804,6 +872,50 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
     if (n_sieve) atomicAdd(out + 3, (unsigned long long)n_sieve);
 }
 
+// Test kernel for the culled stream kernel: one lane per ray evaluates the group test exactly as
+// the kernel does (per lane, before the OR over the wave) and, for every group it would cull,
+// the literal discriminant of the group's spheres under both float profiles.
+// out[0]: (ray, sphere) pairs culled with a non-negative discriminant (must stay 0);
+// out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs tested.  blockDim.x = 256.
+__global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, const float* rays, int n_rays,
+                                                           unsigned long long* out)
+{
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = ray < n_rays;
+    Path p;
+    p.ox = live ? rays[6 * ray + 0] : 0.f; p.oy = live ? rays[6 * ray + 1] : 0.f; p.oz = live ? rays[6 * ray + 2] : 0.f;
+    p.dx = live ? rays[6 * ray + 3] : 1.f; p.dy = live ? rays[6 * ray + 4] : 0.f; p.dz = live ? rays[6 * ray + 5] : 0.f;
+    unsigned bad = 0, culled = 0, tested = 0;
+    const float a_s = dot3<false>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+    const float a_f = dot3<true>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+    const SieveRay srb = sieve_ray(p, a_s, true, RT_CULL_MARGIN_O);
+    const int ngroups = P.n_pad / RT_CULL_GROUP;
+    for (int g0 = 0; g0 < ngroups; g0 += RT_CHUNK) {  // 32 bounding spheres at a time
+        const uint32_t rej = sieve_chunk<RT_GROUP_SGPR>((ConstGeomPtr)(const void*)(P.bounds) + g0, srb);
+        for (int n = 0; n < RT_CHUNK && g0 + n < ngroups && live; n++) {
+            const int first = (g0 + n) * RT_CULL_GROUP;
+            if (first >= P.sphere_count) break;
+            tested++;
+            if (!((rej >> (31 - n)) & 1u)) continue;
+            culled++;
+            for (int k = first; k < first + RT_CULL_GROUP && k < P.sphere_count; k++) {
+                const float4 g = *reinterpret_cast<const float4*>(P.spheres + P.perm[k]);
+                const float ocx = p.ox - g.x, ocy = p.oy - g.y, ocz = p.oz - g.z;
+                const float bs = 2.0f * dot3<false>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
+                const float cs = mad<false>(-g.w, g.w, dot3<false>(ocx, ocy, ocz, ocx, ocy, ocz));
+                const float ds = mad<false>(bs, bs, -((4.0f * a_s) * cs));
+                const float bf = 2.0f * dot3<true>(ocx, ocy, ocz, p.dx, p.dy, p.dz);
+                const float cf = mad<true>(-g.w, g.w, dot3<true>(ocx, ocy, ocz, ocx, ocy, ocz));
+                const float df = mad<true>(bf, bf, -((4.0f * a_f) * cf));
+                if (!(ds < 0.0f) || !(df < 0.0f)) bad++;
+            }
+        }
+    }
+    if (bad) atomicAdd(out + 0, (unsigned long long)bad);
+    if (culled) atomicAdd(out + 1, (unsigned long long)culled);
+    if (tested) atomicAdd(out + 2, (unsigned long long)tested);
+}
+
 // ------------------------------------------------------------------- resolve
 
 // colour = unorm8(accum.rgb / divisor) over the rendered region (shader.comp:129-132).
@@ -843,13 +955,13 @@ __global__ void rt_math_probe_kernel(int op, const float* a, const float* b, con
 
 // ------------------------------------------------------------------ launchers
 
-template <bool FUSED, bool RECORD, bool SGEOM>
+template <bool FUSED, bool RECORD, int MODE>
 static hipError_t launch_stream(const RtParams& P, int blocks, int threads, size_t lds, hipStream_t st)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD, SGEOM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((rt_stream_kernel<FUSED, RECORD, SGEOM>), dim3(blocks), dim3(threads), lds, st, P);
+    hipLaunchKernelGGL((rt_stream_kernel<FUSED, RECORD, MODE>), dim3(blocks), dim3(threads), lds, st, P);
     return hipGetLastError();
 }
 
@@ -866,22 +978,37 @@ size_t rt_stream_lds_bytes(int n_lds, int threads)
            (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
 }
 
-hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, bool sgeom, int blocks, int threads,
+// mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0)
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
     const size_t lds = rt_stream_lds_bytes(P.n_lds, threads);
-    if (P.n_lds == 0) sgeom = true;  // nothing staged: the sieve must read global memory
+    if (mode == 2) {
+        if (record)
+            return fused ? launch_stream<true, true, 2>(P, blocks, threads, lds, st)
+                         : launch_stream<false, true, 2>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, false, 2>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 2>(P, blocks, threads, lds, st);
+    }
+    if (P.n_lds == 0) mode = 1;  // nothing staged: the sieve must read global memory
     if (record && P.n_lds)  // the debug twin takes the LDS path when there is one
-        return fused ? launch_stream<true, true, false>(P, blocks, threads, lds, st)
-                     : launch_stream<false, true, false>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, true, 0>(P, blocks, threads, lds, st)
+                     : launch_stream<false, true, 0>(P, blocks, threads, lds, st);
     if (record)
-        return fused ? launch_stream<true, true, true>(P, blocks, threads, lds, st)
-                     : launch_stream<false, true, true>(P, blocks, threads, lds, st);
-    if (sgeom)
-        return fused ? launch_stream<true, false, true>(P, blocks, threads, lds, st)
-                     : launch_stream<false, false, true>(P, blocks, threads, lds, st);
-    return fused ? launch_stream<true, false, false>(P, blocks, threads, lds, st)
-                 : launch_stream<false, false, false>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, true, 1>(P, blocks, threads, lds, st)
+                     : launch_stream<false, true, 1>(P, blocks, threads, lds, st);
+    if (mode == 1)
+        return fused ? launch_stream<true, false, 1>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 1>(P, blocks, threads, lds, st);
+    return fused ? launch_stream<true, false, 0>(P, blocks, threads, lds, st)
+                 : launch_stream<false, false, 0>(P, blocks, threads, lds, st);
+}
+
+hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
+                                hipStream_t st)
+{
+    hipLaunchKernelGGL(rt_cull_audit_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, st, P, rays, n_rays, out);
+    return hipGetLastError();
 }
 
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st)

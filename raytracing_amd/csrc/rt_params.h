@@ -26,6 +26,10 @@ constexpr int RT_MAX_LDS_SPHERES = RT_MAX_LDS;
 constexpr int RT_MAX_SGPR_SPHERES = 2048;
 // Relative safety margin of the sieve (2^-16 = 256 ulp): see sieve_chunk in rt_kernels.hip.
 constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
+// Culled kernel: spheres per culling group, and the relative margin on o.o of the group test
+// (2^-9; see build_culled in rt_api.cpp for why it is larger than the sieve's).
+constexpr int RT_CULL_GROUP = 8;
+constexpr float RT_CULL_MARGIN_O = 0.001953125f;
 // Pixels a wave takes from a work queue at a time (one 8x8 tile).
 #ifndef RT_SPAN_PIXELS
 #define RT_SPAN_PIXELS 64
@@ -74,6 +78,10 @@ struct RtParams {
     const float4* geom;          // pair-packed sieve geometry: {cx0,cx1,cy0,cy1},{cz0,cz1,w0,w1}
     const float* radius;         // radii, n_pad entries (read by the literal test of the walk)
     const float2* materials;     // material extension: {kind, param} per sphere; null = all kind 0
+    // culled kernel only: geom/radius above are the spatially sorted copies, and
+    const float4* bounds;        // pair-packed like geom: bounding sphere of every group of 8 slots,
+                                 // padded to a multiple of 64 groups with never-touched entries
+    const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
     unsigned* work_counter;      // RT_WORK_BYTES block of queue counters; all zero between launches

@@ -20,6 +20,7 @@ KERNEL_STREAM = 0
 KERNEL_TILE = 1
 KERNEL_STREAM_SGPR = 2
 KERNEL_STREAM_LDS = 3
+KERNEL_STREAM_CULLED = 4
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1
 CLEAR_NEVER = 2
@@ -183,6 +184,13 @@ class Renderer:
         out = (C.c_uint64 * 4)()
         N.check(N.lib().rt_debug_sieve_audit(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0], out))
         return {"missed_strict": int(out[0]), "missed_fused": int(out[1]), "exact": int(out[2]), "passed": int(out[3])}
+
+    def cull_audit(self, rays: np.ndarray) -> dict:
+        """rays: (n, 6) float32 origin+direction; see rt_debug_cull_audit in include/rt_hip.h."""
+        arr = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = (C.c_uint64 * 3)()
+        N.check(N.lib().rt_debug_cull_audit(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0], out))
+        return {"missed": int(out[0]), "culled": int(out[1]), "tested": int(out[2])}
 
     def debug_math(self, op: int, a, b=None, c=None) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)

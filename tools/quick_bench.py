@@ -33,7 +33,7 @@ def main():
     with rt.Renderer(w, h) as r:
         r.set_scene(scene, frame_count=1)
         print(r.info())
-        for kname, kernel in (("lds", 3), ("sgpr", 2), ("tile", 1)):
+        for kname, kernel in (("lds", 3), ("sgpr", 2), ("culled", 4), ("tile", 1)):
             for pname, profile in (("strict", 0), ("fused", 1)):
                 r.set_kernel(kernel)
                 r.set_profile(profile)
