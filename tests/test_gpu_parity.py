@@ -493,3 +493,30 @@ def test_ties_and_degenerate_spheres(rt, default_scene):
     hits = crec["hit"][crec["hit"] >= 0]
     assert 1 in hits and 40 not in hits          # the duplicate never wins a tie
     assert 52 not in hits                         # radius 0 is never hit
+
+
+@pytest.mark.parametrize("size", [(8, 8), (7, 20), (20, 7), (9, 17), (1000, 24), (24, 1000), (8200, 16)])
+def test_odd_image_sizes(rt, default_scene, size):
+    """Sizes that are not multiples of 8 (remainder pixels are never rendered), a single tile,
+    no tile at all, very wide and very tall images."""
+    w, h = size
+    acc, col, cnt = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=2, depth=6)
+    cacc, ccol, crays = _render_cpu(default_scene, w, h, profile=0, n_frames=2, depth=6)
+    assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and cnt["rays"] == crays
+    assert cnt["paths"] == (w // 8) * (h // 8) * 64 * 2
+
+
+def test_large_image_stream_equals_tile(rt, default_scene):
+    """8192x4096 (half a million tiles: the tile-index division by multiplication at scale)."""
+    w, h = 8192, 4096
+    with rt.Renderer(w, h) as r:
+        r.set_max_depth(4)
+        r.set_scene(default_scene, frame_count=1)
+        r.dispatch(1)
+        a0, n0 = r.read_accum(), r.counters()["rays"]
+        r.reset_counters()
+        r.set_kernel(1)
+        r.dispatch(1)
+        a1, n1 = r.read_accum(), r.counters()["rays"]
+    assert np.array_equal(_bits(a0), _bits(a1)) and n0 == n1
+    assert np.all(a0[..., 3] == 1.0)
