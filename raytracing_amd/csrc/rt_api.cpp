@@ -876,6 +876,11 @@ int rt_get_counters(rt_context* c, rt_counters* out)
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) rays += slots[i * RT_RAY_SLOT_STRIDE];
     int count = 0;
     if (c->have_ubo) memcpy(&count, c->ubo + 60, 4);
+#ifdef RT_COUNT_PASSES
+    unsigned long long passes = 0;
+    for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passes += slots[i * RT_RAY_SLOT_STRIDE + 1];
+    fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)rays / passes : 0.0);
+#endif
     out->rays = rays;
     out->sphere_tests = rays * (uint64_t)std::max(0, count);
     out->paths = c->paths;

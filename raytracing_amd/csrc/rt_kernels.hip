@@ -625,6 +625,9 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned nrays = 0;
+#ifdef RT_COUNT_PASSES
+    unsigned npasses = 0;  // experiment: passes over the sphere list, added to the word after the ray counter
+#endif
     float d0x = 0.f, d0y = 0.f, d0z = 0.f;  // camera-ray direction of the lane's pixel
     rt_record* rec = nullptr;
     Path p;
@@ -688,6 +691,9 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
             start = false;
         }
 
+#ifdef RT_COUNT_PASSES
+        npasses++;
+#endif
         // ---- Trace(): sieve + candidate walk
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
@@ -806,6 +812,11 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         }
     }
     if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave);
+#ifdef RT_COUNT_PASSES
+    if (lane == 0)
+        atomicAdd(P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 1,
+                  (unsigned long long)npasses);
+#endif
 
     // The last workgroup to get here puts the work counters back to zero for the next launch:
     // every other workgroup has already seen them run out, so nobody reads them again.  "Last"
