@@ -14,8 +14,16 @@
  *     known-answer vectors (tests/golden/rng_kat.json);
  *   - the host vec3 helpers are pinned against the glm 1.0.0 headers vendored
  *     in the reference (oracle/glm_probe.cpp -> oracle/_ref/glm_probe);
- *   - the floating-point path of the shader is PARITY UNPINNED: no output of
- *     the reference exists to compare with.  GLSL leaves FMA contraction,
+ *   - the one rendered output the reference ships, thumbnail.png (a screenshot at
+ *     an unrecorded camera pose), pins what in it does not depend on the pose: the
+ *     converged sky pixel and two sphere surfaces that mirror the sky
+ *     (tests/golden/thumbnail_sky.json), i.e. sky * 0.15, contribution *= albedo,
+ *     the /(frameCount+1) resolve and the rounding of the rgba8 store;
+ *   - at the camera pose recovered for that screenshot (tests/golden/thumbnail_pose.json,
+ *     tools/recover_thumbnail_pose.py) this oracle reproduces it to PSNR 24.7 dB per
+ *     pixel, 30.5 dB after 8x box filtering, 77 % of the pixels equal: image tolerance;
+ *   - at the bit level the floating-point path of the shader stays PARITY UNPINNED: no
+ *     output of the reference fixes the rounding.  GLSL leaves FMA contraction,
  *     inversesqrt precision and uint->float rounding open; this file fixes
  *     them in writing (see "float profiles" below).
  *
