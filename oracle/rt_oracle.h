@@ -8,8 +8,8 @@
  * call this file; only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg use it, and only as the checker or the reported baseline.
  *
- * PINNING STATUS.  The reference ships no tests, fixtures or golden images and
- * cannot be built or run in this environment (Vulkan + MSVC only), so:
+ * PINNING STATUS.  The reference ships no tests or fixtures -- one screenshot is all the
+ * output it holds -- and cannot be built or run in this environment (Vulkan + MSVC only), so:
  *   - the integer RNG stream (wang_hash / seed) is pinned by hand-evaluated
  *     known-answer vectors (tests/golden/rng_kat.json);
  *   - the host vec3 helpers are pinned against the glm 1.0.0 headers vendored
