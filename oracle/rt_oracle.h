@@ -20,8 +20,8 @@
  *     (tests/golden/thumbnail_sky.json), i.e. sky * 0.15, contribution *= albedo,
  *     the /(frameCount+1) resolve and the rounding of the rgba8 store;
  *   - at the camera pose recovered for that screenshot (tests/golden/thumbnail_pose.json,
- *     tools/recover_thumbnail_pose.py) this oracle reproduces it to PSNR 24.7 dB per
- *     pixel, 30.5 dB after 8x box filtering, 77 % of the pixels equal: image tolerance;
+ *     tools/recover_thumbnail_pose.py) this oracle reproduces it to PSNR 27.2 dB per
+ *     pixel, 33.5 dB after 8x box filtering, 77 % of the pixels equal: image tolerance;
  *   - at the bit level the floating-point path of the shader stays PARITY UNPINNED: no
  *     output of the reference fixes the rounding.  GLSL leaves FMA contraction,
  *     inversesqrt precision and uint->float rounding open; this file fixes

@@ -523,8 +523,8 @@ def test_large_image_stream_equals_tile(rt, default_scene):
 
 
 def test_kernels_reproduce_the_reference_screenshot(rt, default_scene):
-    """The reference's thumbnail.png at its recovered camera pose, 1024 frames on the GPU: PSNR >= 27 dB
-    against the screenshot reduced 4x, >= 30 dB reduced 8x (see the oracle's twin of this test for
+    """The reference's thumbnail.png at its recovered camera pose, 1024 frames on the GPU: PSNR >= 29.5 dB
+    against the screenshot reduced 4x, >= 32.5 dB reduced 8x (see the oracle's twin of this test for
     what the residual is)."""
     import thumbnail as T
 
@@ -535,4 +535,4 @@ def test_kernels_reproduce_the_reference_screenshot(rt, default_scene):
         r.dispatch(1024)
         acc = r.read_accum()
     p4, p8, sky = T.compare(acc, 1024)
-    assert p4 >= 27.0 and p8 >= 30.0 and sky >= 0.99, (p4, p8, sky)
+    assert p4 >= 29.5 and p8 >= 32.5 and sky >= 0.99, (p4, p8, sky)

@@ -241,8 +241,8 @@ def test_sky_mirrored_by_a_sphere_equals_the_reference_screenshot(default_scene)
 def test_oracle_reproduces_the_reference_screenshot(default_scene):
     """thumbnail.png at the pose recovered for it (tools/recover_thumbnail_pose.py; five fitted
     numbers against 1.9 M pixels): primary visibility, mirror reflections of reflections, emitters
-    and sky all land where the reference drew them.  Stated tolerance: PSNR >= 26 dB against the
-    screenshot reduced 4x, >= 29 dB reduced 8x, sky/non-sky agreement >= 99 % of the reduced
+    and sky all land where the reference drew them.  Stated tolerance: PSNR >= 28.5 dB against the
+    screenshot reduced 4x, >= 31.5 dB reduced 8x, sky/non-sky agreement >= 99 % of the reduced
     pixels.  What is left is misalignment at the edges of mirrored highlights and the blur of the
     close-up sphere, which the screenshot shows with a ring-shaped kernel (constant roughness, the
     commented-out line res/shaders/shader.comp:101) where the shipped shader draws it at random."""
@@ -252,4 +252,4 @@ def test_oracle_reproduces_the_reference_screenshot(default_scene):
     frames = 8
     acc, _, _ = O.render(ubo, default_scene.spheres, T.WIDTH, T.HEIGHT, n_frames=frames, threads=8)
     p4, p8, sky = T.compare(acc, frames)
-    assert p4 >= 26.0 and p8 >= 29.0 and sky >= 0.99, (p4, p8, sky)
+    assert p4 >= 28.5 and p8 >= 31.5 and sky >= 0.99, (p4, p8, sky)
