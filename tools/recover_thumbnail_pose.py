@@ -11,7 +11,8 @@ that the image becomes a golden output for the whole path:
      mask (which pixels show the sky colour) on a 120x64 grid, first hits only, numpy;
   2. refine: Nelder-Mead on the same score at 476x253;
   3. refine: Nelder-Mead on the mean absolute colour difference between the 6x box-filtered
-     screenshot and the CPU oracle's render (half resolution, 4 frames).
+     screenshot and the CPU oracle's render (half resolution, 4 frames);
+  4. refine: the same on full-size renders (3 frames), 3x box-filtered, differences capped at 96.
 
 Result -> tests/golden/thumbnail_pose.json.  Needs /root/reference/thumbnail.png and the oracle.
 usage: python tools/recover_thumbnail_pose.py [seed=1] [coarse_samples=200000]
@@ -112,6 +113,26 @@ def main():
         x = minimize(colour_loss, x, method="Nelder-Mead",
                      options=dict(xatol=1e-5, fatol=1e-5, maxiter=200, initial_simplex=simplex)).x
     print("colour", colour_loss(x), x)
+
+    # 4. colour, full size
+    full = np.array(Image.open(THUMB).convert("RGB")).astype(np.float64)[:1008, :1904]
+    fulld = down(full, 3)
+
+    def full_loss(p):
+        ubo = scene.camera.copy()
+        f, r, u = O.camera_basis(float(p[3]), float(p[4]))
+        ubo["camera_forward"][0], ubo["camera_right"][0], ubo["camera_up"][0] = f, r, u
+        ubo["camera_position"][0] = p[:3]
+        ubo["frameCount"][0] = 1
+        acc, _, _ = O.render(ubo, scene.spheres, W0, H0, n_frames=3, threads=os.cpu_count() or 1, max_depth=16)
+        img = np.clip(acc[:1008, :1904, :3] / 3, 0, 1) * 255
+        return np.minimum(np.abs(down(img, 3) - fulld), 96).mean()
+
+    for rnd in range(2):
+        simplex = x + np.vstack([np.zeros(5), np.diag([0.01, 0.01, 0.01, 0.08, 0.08]) * 0.5 ** rnd])
+        x = minimize(full_loss, x, method="Nelder-Mead",
+                     options=dict(xatol=1e-6, fatol=1e-6, maxiter=150, initial_simplex=simplex)).x
+    print("full size", full_loss(x), x)
     out = {
         "source": "camera pose of the reference's thumbnail.png recovered by tools/recover_thumbnail_pose.py",
         "image_size": [W0, H0],
