@@ -55,8 +55,8 @@ enum {
     RT_KERNEL_STREAM_CULLED = 4 /* STREAM over a spatially sorted copy of the sphere list: groups of 8
                                   spheres whose bounding sphere no ray of the wave can touch are
                                   skipped.  Not brute force any more (the step the reference's
-                                  readme.md:38 names, a spatial hierarchy); same bits.  Scenes of more
-                                  than 4096 traced spheres fall back to RT_KERNEL_STREAM.           */
+                                  readme.md:38 names, a spatial hierarchy); same bits.  Scenes of fewer
+                                  than 97 or more than 4096 traced spheres run RT_KERNEL_STREAM.    */
 };
 
 /* When the accumulation texel is zeroed. */

@@ -423,11 +423,14 @@ int ensure_culled(rt_context* c, int count, int n_pad)
 }
 
 // The culled kernel's view of the scene: the sorted copies in place of geom/radius, plus bounds
-// and perm.  False when the scene does not qualify (empty, or too large to stage in LDS).
-int use_culled(rt_context* c, RtParams* P, bool* on)
+// and perm.  False when the scene does not qualify: empty, too large to stage in LDS, or (unless
+// `force`, which the audit uses) so small that the group test costs more than it saves -- measured,
+// the 40-sphere default scene runs 12 % slower culled.
+int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false)
 {
     *on = false;
     if (P->n_pad == 0 || P->n_pad > RT_MAX_LDS_SPHERES) return RT_OK;
+    if (!force && P->n_pad < 128) return RT_OK;
     int rc = ensure_culled(c, P->sphere_count, P->n_pad);
     if (rc != RT_OK) return rc;
     P->geom = c->d_cgeom;
@@ -973,7 +976,7 @@ int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t o
     int rc = make_params(c, 1, &P);
     if (rc != RT_OK) return rc;
     bool on = false;
-    rc = use_culled(c, &P, &on);
+    rc = use_culled(c, &P, &on, true);
     if (rc != RT_OK) return rc;
     if (!on) return fail(RT_E_INVALID, "the culled kernel does not apply to this scene (%d spheres)", P.sphere_count);
     float* d_rays = nullptr;

@@ -61,10 +61,11 @@ def test_culled_images_match_oracle(rt, default_scene, rtiow_scene, profile):
         assert cnt["rays"] == crays
 
 
-@pytest.mark.parametrize("count", [0, 1, 7, 8, 9, 31, 32, 33, 65, 513, 1025, 4096])
+@pytest.mark.parametrize("count", [0, 1, 33, 96, 97, 100, 121, 128, 129, 255, 481, 513, 1025, 4096])
 def test_culled_sphere_counts(rt, count):
-    """Ragged groups and chunks, the 512-sphere supergroup boundary, the largest scene the culled
-    kernel takes; sphere_count smaller than the upload (the sorted copy holds the traced ones only)."""
+    """Ragged groups and chunks, the 512-sphere supergroup boundary, the smallest (97) and largest
+    (4096) scenes the culled kernel takes (smaller ones run the brute-force kernel);
+    sphere_count smaller than the upload (the sorted copy holds the traced ones only)."""
     scene = rt.Scene.generate(rt.KIND_CUBE, max(count, 3) + 5, 11)
     acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=0, kernel=CULLED, n_frames=2, depth=6, sphere_count=count)
     cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=0, n_frames=2, depth=6, sphere_count=count)
@@ -83,7 +84,7 @@ def test_culled_ties_degenerates_and_records(rt):
     """Duplicates must still resolve to the lowest original index although the sorted list visits
     them in another order; non-finite spheres keep their group always evaluated; the per-bounce
     records (original indices) equal the oracle's."""
-    scene = rt.Scene.generate(rt.KIND_CUBE, 96, 17)
+    scene = rt.Scene.generate(rt.KIND_CUBE, 160, 17)
     sph = scene.spheres
     sph[40] = sph[1]
     sph[2] = sph[41]
