@@ -253,3 +253,21 @@ def test_oracle_reproduces_the_reference_screenshot(default_scene):
     acc, _, _ = O.render(ubo, default_scene.spheres, T.WIDTH, T.HEIGHT, n_frames=frames, threads=8)
     p4, p8, sky = T.compare(acc, frames)
     assert p4 >= 28.5 and p8 >= 31.5 and sky >= 0.99, (p4, p8, sky)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/res/scenes/scene.yaml"), reason="needs the reference's 1400-sphere file")
+def test_screenshot_says_forty_spheres_are_traced():
+    """The reference's scene file holds 1400 spheres and camera[4] = 40; the shader loops to
+    sphereCount.  Against the screenshot, tracing more than 40 is visibly wrong."""
+    import raytracing_amd as rt
+    import thumbnail as T
+
+    scene = rt.Scene.load("/root/reference/res/scenes/scene.yaml")
+    assert len(scene.spheres) == 1400 and scene.sphere_count == 40
+    ubo = T.posed_ubo(scene)
+    p8 = {}
+    for count in (40, 48):
+        ubo["sphereCount"][0] = count
+        acc, _, _ = O.render(ubo, scene.spheres, T.WIDTH, T.HEIGHT, n_frames=4, threads=8)
+        p8[count] = T.compare(acc, 4)[1]
+    assert p8[40] >= 31.0 and p8[48] <= 25.0, p8
