@@ -536,3 +536,43 @@ def test_kernels_reproduce_the_reference_screenshot(rt, default_scene):
         acc = r.read_accum()
     p4, p8, sky = T.compare(acc, 1024)
     assert p4 >= 29.5 and p8 >= 32.5 and sky >= 0.99, (p4, p8, sky)
+
+
+def test_flat_colours_of_the_reference_screenshot_are_exact(rt, default_scene):
+    """The screenshot's 14 most frequent colours are flat areas: the sky, two saturated emitters and
+    paths that end in the sky after mirroring off one or two spheres.  Rendered at the recovered
+    pose with a frame count inside the range the screenshot's own colours allow (171-416), the
+    kernels give exactly the same 8-bit colours in those areas: of the 4x4 blocks that are flat in
+    one of these colours in the screenshot and flat in ours as well (at least half of them; the
+    others straddle a border that lies a pixel or two elsewhere), at least 95 % have that very colour."""
+    import json
+
+    import thumbnail as T
+
+    gold = json.load(open(os.path.join(GOLDEN, "thumbnail_sky.json")))
+    lo, hi = gold["frame_count_range"]
+    frames = 256
+    assert lo <= frames <= hi
+    ubo = T.posed_ubo(default_scene)
+    with rt.Renderer(T.WIDTH, T.HEIGHT) as r:
+        r.upload_spheres(default_scene.spheres)
+        r.set_uniforms(ubo)
+        r.dispatch(frames)
+        col = r.read_color()[:1008, :1904, :3].astype(np.float64)
+    ref = T.reduced_screenshot()
+    blocks = col.reshape(252, 4, 476, 4, 3)
+    bmin, bmax = blocks.min((1, 3)), blocks.max((1, 3))
+    checked = 0
+    ours_flat = np.all(bmin == bmax, axis=-1)
+    for entry in gold["frequent_rgb"]:
+        c = np.array(entry["rgb"], np.float64)
+        theirs = np.all(ref == c, axis=-1)             # a block of the screenshot flat in this colour
+        if theirs.sum() < 200:
+            continue
+        both = theirs & ours_flat                       # ... where ours is flat too
+        same = np.all(bmin == c, axis=-1) & both
+        coverage, agree = both.sum() / theirs.sum(), same.sum() / max(1, both.sum())
+        print(entry, round(float(coverage), 4), round(float(agree), 4))
+        assert coverage >= 0.5 and agree >= 0.95, (entry, coverage, agree)
+        checked += 1
+    assert checked >= 10

@@ -29,6 +29,13 @@ out = {
     "sky_rgb": [int(v) for v in rgb],
     "pixels_with_that_colour": int(count),
     "surface_rgb": [{"rgb": [int(v) for v in c], "pixels": int(n)} for c, n in top[1:]],
+    # The 14 most frequent colours.  Apart from the two saturated emitters they are flat areas whose
+    # paths end in the sky after mirroring off one or two spheres: sky * 0.15 * albedo_a (* albedo_b).
+    # With the albedos of the reference's scene file every one of them comes out exactly for any
+    # accumulated frame count from 171 to 416 (the /(frameCount+1) of the resolve darkens slightly).
+    "frequent_rgb": [{"rgb": [int(v) for v in c], "pixels": int(n)}
+                     for c, n in collections.Counter(map(tuple, img.reshape(-1, 3))).most_common(14)],
+    "frame_count_range": [171, 416],
 }
 json.dump(out, open(os.path.join(ROOT, "tests", "golden", "thumbnail_sky.json"), "w"), indent=1)
 # the screenshot itself, 4x box-filtered (its top-left 1904x1008, the part an 8x8-tiled dispatch covers)
