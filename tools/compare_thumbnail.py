@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Full-size comparison with the reference's thumbnail.png (how the figures in DESIGN.md and
+"""Full-size comparison with the reference's thumbnail.png (how the figures quoted for the screenshot comparison and in
 tests/golden/thumbnail_pose.json were measured).  Two steps, because the screenshot exists only
 where the reference tree is and the GPU only on the GPU box:
 
