@@ -85,7 +85,7 @@ void rto_sincos_2pi(float u, float out[2])
 #undef MAD
 
 typedef int (*shade_fn)(const rto_ubo*, const rto_sphere*, int, int, int, int, int, int32_t,
-                        float*, rto_record*, const float*);
+                        float*, rto_record*, const float*, float);
 
 /* One row of 8x8 tiles, every frame of the job, for one float profile.  The
    fused copy is cloned for CPUs with an FMA unit so fmaf() is one instruction
@@ -107,7 +107,7 @@ typedef int (*shade_fn)(const rto_ubo*, const rto_sphere*, int, int, int, int, i
                     if (clear) acc[0] = acc[1] = acc[2] = acc[3] = 0.0f; /* shader.comp:79-81 */ \
                     float light[3];                                                              \
                     rays += (uint64_t)SHADE(ubo, spheres, W, H, job->max_depth, x, y, frame,    \
-                                            light, NULL, job->materials);                        \
+                                            light, NULL, job->materials, job->const_roughness); \
                     /* shader.comp:126-128: vec4(light, 1.0) + accumulated */                    \
                     acc[0] = light[0] + acc[0];                                                  \
                     acc[1] = light[1] + acc[1];                                                  \
@@ -208,7 +208,7 @@ int rto_trace_crop(const rto_ubo* ubo, const rto_sphere* spheres, int n_buffer_s
                 size_t p = ((size_t)j * h + (size_t)(y - y0)) * w + (size_t)(x - x0);
                 float light[3];
                 shade(ubo, spheres, job->width, job->height, job->max_depth, x, y, frame, light,
-                      out + p * (size_t)job->max_depth, job->materials);
+                      out + p * (size_t)job->max_depth, job->materials, job->const_roughness);
                 if (light_out) memcpy(light_out + 3 * p, light, sizeof light);
             }
     }

@@ -90,6 +90,10 @@ typedef struct rto_job {
     int clear_mode;           /* RTO_CLEAR_*                                             */
     int n_threads;            /* host threads (<=1: run on the calling thread)          */
     const float* materials;   /* material extension: {kind, param} per sphere, or NULL    */
+    float const_roughness;    /* > 0: the constant-roughness variant the shader keeps commented
+                                 out (shader.comp:101: Material(sphere.color, <constant>)), used
+                                 only to explain the reference's screenshot; 0 = the shipped rule
+                                 (shader.comp:99-100, roughness = rand * 0.02)                  */
 } rto_job;
 
 /* def.glsl:40-48 */

@@ -29,6 +29,7 @@ class Job(C.Structure):
         ("n_frames", C.c_int), ("frame_stride", C.c_int),
         ("clear_mode", C.c_int), ("n_threads", C.c_int),
         ("materials", C.c_void_p),
+        ("const_roughness", C.c_float),
     ]
 
 
@@ -73,10 +74,11 @@ def seed(px: int, py: int, frame: int, bounce: int) -> int:
     return int(lib().rto_seed(px, py, frame, bounce))
 
 
-def _job(width, height, max_depth, profile, n_frames, stride, clear, rows, threads, materials=None) -> Job:
+def _job(width, height, max_depth, profile, n_frames, stride, clear, rows, threads, materials=None,
+         const_roughness=0.0) -> Job:
     r0, r1 = rows if rows else (0, 0)
     ptr = materials.ctypes.data if materials is not None else None
-    return Job(width, height, r0, r1, max_depth, profile, n_frames, stride, clear, threads, ptr)
+    return Job(width, height, r0, r1, max_depth, profile, n_frames, stride, clear, threads, ptr, const_roughness)
 
 
 def _materials(materials, n):
@@ -90,7 +92,7 @@ def _materials(materials, n):
 
 def render(ubo: np.ndarray, spheres: np.ndarray, width: int, height: int, *, max_depth=50, profile=STRICT,
            n_frames=1, frame_stride=1, clear_mode=CLEAR_REFERENCE, rows=None, threads=1, accum=None,
-           materials=None):
+           materials=None, const_roughness=0.0):
     """Returns (accum HxWx4 f32, color HxWx4 u8, rays).  ubo: 80-byte record array (frameCount = first frame)."""
     ubo_b = np.ascontiguousarray(ubo).tobytes()
     assert len(ubo_b) == 80
@@ -99,7 +101,8 @@ def render(ubo: np.ndarray, spheres: np.ndarray, width: int, height: int, *, max
     col = np.zeros((height, width, 4), np.uint8)
     rays = C.c_uint64()
     mats = _materials(materials, len(sph))
-    job = _job(width, height, max_depth, profile, n_frames, frame_stride, clear_mode, rows, threads, mats)
+    job = _job(width, height, max_depth, profile, n_frames, frame_stride, clear_mode, rows, threads, mats,
+               const_roughness)
     rc = lib().rto_render(ubo_b, sph.ctypes.data_as(C.c_void_p), len(sph), C.byref(job),
                           acc.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), C.byref(rays))
     if rc:

@@ -271,3 +271,25 @@ def test_screenshot_says_forty_spheres_are_traced():
         acc, _, _ = O.render(ubo, scene.spheres, T.WIDTH, T.HEIGHT, n_frames=4, threads=8)
         p8[count] = T.compare(acc, 4)[1]
     assert p8[40] >= 31.0 and p8[48] <= 25.0, p8
+
+
+def test_screenshot_was_taken_with_the_constant_roughness_variant(default_scene):
+    """What is left between the oracle and the screenshot sits on the close-up sphere, whose blur is
+    ring-shaped in the screenshot.  The shader keeps a constant-roughness line commented out
+    (res/shaders/shader.comp:101); with a constant 0.01 -- the mean of the shipped rand * 0.02 -- the
+    oracle fits that sphere about 3 dB better, with 0.02 about 6 dB worse: the screenshot comes from
+    that variant, and the residual is the roughness rule, not the path."""
+    import thumbnail as T
+
+    ubo = T.posed_ubo(default_scene)
+    rec, _ = O.trace_crop(ubo, default_scene.spheres, T.WIDTH, T.HEIGHT, 0, 0, 1904, 1008, max_depth=1)
+    close_up = T.box((rec["hit"][0, :, :, 0] == 11)[..., None].astype(np.float64), 4)[..., 0] == 1.0
+    assert 0.3 < close_up.mean() < 0.45
+    ref = T.reduced_screenshot()
+    fit = {}
+    for rough in (0.0, 0.01, 0.02):
+        acc, _, _ = O.render(ubo, default_scene.spheres, T.WIDTH, T.HEIGHT, n_frames=6, threads=8, const_roughness=rough)
+        img = T.box(np.clip(acc[:1008, :1904, :3] / np.float32(6), 0.0, 1.0).astype(np.float64) * 255.0, 4)
+        fit[rough] = T.psnr(img[close_up], ref[close_up])
+    assert fit[0.01] >= fit[0.0] + 1.5 and fit[0.02] <= fit[0.0] - 3.0, fit
+    assert fit[0.01] >= 31.0, fit
