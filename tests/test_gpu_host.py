@@ -116,3 +116,25 @@ def test_headless_renders_a_scene_file_with_materials(tmp_path):
     got = _read_ppm(out)
     assert np.array_equal(got, color[..., :3])
     assert not np.array_equal(got, plain[..., :3])
+
+
+def test_headless_reproduces_the_reference_screenshot(tmp_path):
+    """The C++ host, end to end: default scene file, the camera pose recovered for the reference's
+    thumbnail.png, 300 frames at the screenshot's size -> the written image matches the screenshot
+    (reduced 4x: PSNR >= 29.5 dB, 8x: >= 32.5 dB)."""
+    import json
+
+    import thumbnail as T
+    from conftest import GOLDEN
+
+    pose = json.load(open(os.path.join(GOLDEN, "thumbnail_pose.json")))
+    out = tmp_path / "thumb.ppm"
+    cmd = [BINARY, "--scene", rt.DEFAULT_SCENE, "--size", f"{T.WIDTH}x{T.HEIGHT}", "--frames", "300",
+           "--position", ",".join(repr(v) for v in pose["position"]), "--yaw", repr(pose["yaw_degrees"]),
+           "--pitch", repr(pose["pitch_degrees"]), "--out", str(out)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = _read_ppm(out).astype(np.float64)[:1008, :1904]
+    ref = T.reduced_screenshot()
+    mine = T.box(got * (301.0 / 300.0), 4)   # the colour image divides by frameCount + 1
+    assert T.psnr(mine, ref) >= 29.5 and T.psnr(T.box(mine, 2), T.box(ref, 2)) >= 32.5
