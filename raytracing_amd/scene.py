@@ -38,6 +38,23 @@ KIND_RTIOW_MATERIALS = 2
 MATERIAL_REFERENCE, MATERIAL_LAMBERTIAN, MATERIAL_METAL, MATERIAL_DIELECTRIC = 0, 1, 2, 3
 
 
+class _SceneView(np.ndarray):
+    """A view of memory owned by a Scene: carries a reference to it (and so do its slices), so the
+    native scene is not freed while some array still looks at its spheres or camera."""
+
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self._owner = getattr(obj, "_owner", None)
+
+
+def _owned(arr: np.ndarray, owner) -> np.ndarray:
+    view = arr.view(_SceneView)
+    view._owner = owner
+    return view
+
+
 class Scene:
     def __init__(self, handle: int):
         self._h = C.c_void_p(handle)
@@ -90,13 +107,13 @@ class Scene:
             return np.zeros(0, SPHERE_DTYPE)
         ptr = N.lib().rt_scene_spheres(self._h)
         buf = (C.c_char * (n * 32)).from_address(ptr)
-        return np.frombuffer(buf, dtype=SPHERE_DTYPE, count=n)
+        return _owned(np.frombuffer(buf, dtype=SPHERE_DTYPE, count=n), self)
 
     @property
     def camera(self) -> np.ndarray:
         ptr = N.lib().rt_scene_ubo(self._h)
         buf = (C.c_char * 80).from_address(ptr)
-        return np.frombuffer(buf, dtype=UBO_DTYPE, count=1)
+        return _owned(np.frombuffer(buf, dtype=UBO_DTYPE, count=1), self)
 
     @property
     def materials(self) -> np.ndarray:
@@ -106,7 +123,7 @@ class Scene:
         if n <= 0 or not ptr:
             return np.zeros((0, 2), np.float32)
         buf = (C.c_float * (n * 2)).from_address(ptr)
-        return np.frombuffer(buf, dtype=np.float32, count=n * 2).reshape(n, 2)
+        return _owned(np.frombuffer(buf, dtype=np.float32, count=n * 2).reshape(n, 2), self)
 
     @property
     def sphere_count(self) -> int:

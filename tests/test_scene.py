@@ -176,6 +176,29 @@ def test_saved_camera_basis_of_the_reference_is_reproduced_bit_for_bit():
     assert not np.array_equal(_bits(np.concatenate([f2, r2, u2])), _bits(saved))
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SCENE), reason="needs the reference's scene file")
+def test_generated_spheres_follow_the_distributions_of_the_reference_file():
+    """The reference appends sphereCount random spheres at every load (src/scene.cpp:20-35); its
+    scene file holds 1360 of them after the 40 traced ones.  The stress-scene generator draws from
+    the same distributions -- centres U(-15,15)^3, radius U(0.5,3), colour U(0,1)^3: two-sample
+    Kolmogorov-Smirnov tests against the reference's own spheres do not tell them apart."""
+    from scipy import stats
+
+    ref_scene = rt.Scene.load(REF_SCENE)          # the views below live as long as their scenes
+    own_scene = rt.Scene.generate(rt.KIND_CUBE, 1403, 5)
+    theirs = ref_scene.spheres[40:].copy()
+    assert len(theirs) == 1360
+    ours = own_scene.spheres[3:].copy()           # 0-2 are the fixed lights
+    samples = [(ours["radius"], theirs["radius"])]
+    for k in range(3):
+        samples.append((ours["center"][:, k].copy(), theirs["center"][:, k].copy()))
+        samples.append((ours["color"][:, k].copy(), theirs["color"][:, k].copy()))
+    for a, b in samples:
+        assert stats.ks_2samp(np.asarray(a, np.float64), np.asarray(b, np.float64)).pvalue > 1e-3
+    assert theirs["radius"].min() >= 0.5 and theirs["radius"].max() <= 3.0
+    assert np.abs(theirs["center"]).max() <= 15.0 and theirs["color"].min() >= 0.0 and theirs["color"].max() <= 1.0
+
+
 def test_update_integrator_matches_oracle_and_glm():
     """Scene::update: frameCount++, semi-implicit Euler with 0.98 damping, reset to 1 when moved > 0.01."""
     lines = [l.split() for l in open(os.path.join(GOLDEN, "glm_probe.txt")) if l.startswith("update")]
