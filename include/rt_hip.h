@@ -74,7 +74,7 @@ typedef struct rt_record {
 
 typedef struct rt_counters {
     uint64_t rays;         /* Trace() calls (res/shaders/shader.comp:96) since the last reset */
-    uint64_t sphere_tests; /* rays x sphereCount                                                */
+    uint64_t sphere_tests; /* sum over dispatches of rays x that dispatch's sphereCount         */
     uint64_t paths;        /* pixel-frames rendered                                             */
 } rt_counters;
 
@@ -206,6 +206,11 @@ int rt_debug_sieve_audit(rt_context* ctx, const float* rays, int n_rays, uint64_
    not negative -- must be 0; out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs
    tested.  No reference counterpart. */
 int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[3]);
+
+/* Test hook: the next stream-kernel launch of this context is not made; that dispatch returns
+   RT_E_HIP and leaves the work-queue counters as a kernel that died half way would.  The
+   dispatch after it must render correctly.  No reference counterpart. */
+int rt_debug_fail_next_launch(rt_context* ctx);
 
 const char* rt_last_error(void);
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int]),
     "rt_debug_sieve_audit": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),
     "rt_debug_cull_audit": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),
+    "rt_debug_fail_next_launch": (C.c_int, [_P]),
     "rt_last_error": (C.c_char_p, []),
     "rt_scene_load": (C.c_int, [C.c_char_p, _PP]),
     "rt_scene_parse": (C.c_int, [C.c_char_p, C.c_size_t, _PP]),

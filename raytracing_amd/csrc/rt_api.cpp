@@ -8,32 +8,21 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
-#include "rt_params.h"
-
-// launchers defined in rt_kernels.hip
-size_t rt_stream_lds_bytes(int n_pad, int threads);
-hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
-                            hipStream_t st);
-hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
-                                hipStream_t st);
-hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
-hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
-                             int y1, float divisor, hipStream_t st);
-hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
-                                 hipStream_t st);
-hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const float* c, float* out,
-                                int n, hipStream_t st);
+#include "rt_internal.h"
 
 namespace {
 
 thread_local std::string g_error;
 
-int fail(int code, const char* fmt, ...)
+}  // namespace
+
+int rt_fail(int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -44,13 +33,24 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+namespace {
+
+#define fail rt_fail
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) return fail(RT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kLdsPerCu = RT_LDS_PER_CU;
+
+// Every entry point that touches the device runs with the context's device current and puts the
+// calling thread's own device back on return.
+#define RT_ON_DEVICE(ctx)                                                                   \
+    RtDeviceGuard guard_((ctx)->device);                                                    \
+    if (guard_.status() != hipSuccess)                                                      \
+        return fail(RT_E_HIP, "hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(guard_.status()))
 
 }  // namespace
 
@@ -100,6 +100,7 @@ struct rt_context {
     int frame_stride = 1;
     int clear_mode = RT_CLEAR_REFERENCE;
     int blocks = 0, threads = 0;  // 0 = automatic
+    bool fail_next_launch = false;  // rt_debug_fail_next_launch
 };
 
 namespace {
@@ -122,26 +123,35 @@ UboView read_ubo(const unsigned char* u)
     return v;
 }
 
-int free_images(rt_context* c)
+void free_images(rt_context* c)
 {
-    if (c->accum_own) HIP_TRY(hipFree(c->accum_own));
-    if (c->color_own) HIP_TRY(hipFree(c->color_own));
+    if (c->accum_own) (void)hipFree(c->accum_own);
+    if (c->color_own) (void)hipFree(c->color_own);
     c->accum_own = nullptr;
     c->color_own = nullptr;
-    return RT_OK;
 }
 
+// New W x H images.  The context is touched only once both allocations have succeeded, so a
+// failure leaves it rendering into the images it had.
 int alloc_images(rt_context* c, int w, int h)
 {
     const size_t px = (size_t)w * h;
-    HIP_TRY(hipMalloc(&c->accum_own, px * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->color_own, px * sizeof(uint32_t)));
+    float4* accum = nullptr;
+    uint32_t* color = nullptr;
+    hipError_t e = hipMalloc(&accum, px * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&color, px * sizeof(uint32_t));
     // The reference leaves a new accumulation image undefined
     // (compute_pipeline.cpp:178-269); zero is one legal instance of that.
-    HIP_TRY(hipMemsetAsync(c->accum_own, 0, px * sizeof(float4), c->stream));
-    HIP_TRY(hipMemsetAsync(c->color_own, 0, px * sizeof(uint32_t), c->stream));
-    c->accum = c->accum_own;
-    c->color = c->color_own;
+    if (e == hipSuccess) e = hipMemsetAsync(accum, 0, px * sizeof(float4), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(color, 0, px * sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) {
+        if (accum) (void)hipFree(accum);
+        if (color) (void)hipFree(color);
+        return fail(RT_E_HIP, "allocating %d x %d images: %s", w, h, hipGetErrorString(e));
+    }
+    free_images(c);
+    c->accum_own = c->accum = accum;
+    c->color_own = c->color = color;
     c->width = w;
     c->height = h;
     return RT_OK;
@@ -155,8 +165,9 @@ unsigned tile_magic(int d)
     return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
 }
 
-// Derived fields: call after sphere_count, n_pad, n_frames and the tile rectangle are set.
-void finish_params(RtParams& P)
+}  // namespace
+
+void rt_finish_params(RtParams& P)
 {
     P.total_pixels = (unsigned)P.tile_cols * (unsigned)P.tile_rows * 64u;
     P.tile_cols_magic = tile_magic(P.tile_cols);
@@ -169,6 +180,8 @@ void finish_params(RtParams& P)
     // Long spans do not: a span held in reserve is a span an idle wave cannot take at the end.
     P.prefetch = (long long)P.n_frames * std::max(P.n_pad, 32) <= 1024 ? 1 : 0;
 }
+
+namespace {
 
 // Fill the launch-independent part of the kernel arguments; validates state.
 int make_params(rt_context* c, int n_frames, RtParams* out)
@@ -197,7 +210,7 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
     P.tile_row0 = r0;
     P.tile_rows = std::max(0, r1 - r0);
     P.n_frames = n_frames;
-    finish_params(P);
+    rt_finish_params(P);
     P.max_depth = c->max_depth;
     P.frame0 = u.frame_count;
     P.frame_stride = c->frame_stride;
@@ -365,28 +378,57 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
     }
 }
 
+void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* threads)
+{
+    rt_stream_geometry(c->cu_count, c->blocks, c->threads, P, blocks, threads);
+}
+
+}  // namespace
+
 // Workgroup size and count of the persistent kernel.  The kernel is bound by VALU issue, which
 // two waves per SIMD already saturate; more waves only add start-up and drain cost (every wave
 // ends with a few half-empty iterations).  Measured on MI355X: 12 waves per CU is the best or
 // within noise of it from 2 to 16 frames per dispatch, 8 when a dispatch gives a wave fewer than
 // 16 lane-fills of paths (one 1080p frame).  Bounded by the LDS one workgroup needs (geometry +
 // per-wave candidate masks).
-void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* threads)
+void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const RtParams& P, int* blocks,
+                        int* threads)
 {
-    int t = c->threads > 0 ? c->threads : (P.n_lds <= 1024 ? 256 : 1024);
+    int t = want_threads > 0 ? want_threads : (P.n_lds <= 1024 ? 256 : 1024);
     t = std::max(64, std::min(1024, t / 64 * 64));
     const size_t lds = rt_stream_lds_bytes(P.n_lds, t);
     const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
-    int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)c->cu_count ? 8 : 12;
+    int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)cu_count ? 8 : 12;
     if (t == 1024) waves_per_cu = 16;  // whole workgroups: one per CU
     int per_cu = std::min<int>(std::max(1, waves_per_cu / (t / 64)), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
     per_cu = std::max(1, per_cu);
-    int b = c->blocks > 0 ? c->blocks : c->cu_count * per_cu;
+    int b = want_blocks > 0 ? want_blocks : cu_count * per_cu;
     const unsigned lanes_needed = (P.total_pixels + (unsigned)t - 1) / (unsigned)t;
     b = (int)std::max(1u, std::min((unsigned)b, lanes_needed));
     *blocks = b;
     *threads = t;
 }
+
+// Spans a wave of the stream kernel takes without asking (RtParams::static_spans).  A dispatch
+// whose spans are short (few frames, few spheres) would otherwise spend longer on its span
+// requests than on tracing: one 1080p frame is 32 400 spans, and requests to one counter
+// complete about 11 ns apart.  Such a dispatch hands every wave 7/8 of its fair share up front,
+// interleaved over the image, and leaves the rest in the queues to even out the finish.  A
+// dispatch with long spans keeps them all in the queues: its requests cost nothing next to the
+// tracing, and the last span a wave holds is the kernel's tail.
+int rt_static_spans(const RtParams& P, int blocks, int threads)
+{
+    static const int forced = [] {
+        const char* e = getenv("RT_DEBUG_STATIC_EIGHTHS");  // development knob: 0..8 eighths of the fair share
+        return e ? std::max(0, std::min(8, atoi(e))) : -1;
+    }();
+    const int eighths = forced >= 0 ? forced : (P.prefetch ? 7 : 0);
+    const unsigned nspans = (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
+    const unsigned waves = (unsigned)blocks * (unsigned)(threads / 64);
+    return (int)((unsigned long long)nspans * eighths / 8 / std::max(1u, waves));
+}
+
+namespace {
 
 // Build and upload the sorted copy of the first `count` spheres unless the device already holds it.
 int ensure_culled(rt_context* c, int count, int n_pad)
@@ -441,6 +483,14 @@ int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false)
     return RT_OK;
 }
 
+// The span counters are only back at zero when a stream kernel has run to its end.  After a
+// launch that failed, or a stream that reported an error, they are zeroed from the host so that
+// the next dispatch does not find its queues "already empty" and render nothing.
+void reset_work(rt_context* c)
+{
+    if (c->d_work) (void)hipMemsetAsync(c->d_work, 0, RT_WORK_BYTES, c->stream);
+}
+
 int launch(rt_context* c, const RtParams& P_in, bool record)
 {
     RtParams P = P_in;
@@ -459,7 +509,8 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
                     P.tile_rows);
     // d_work (span counters, workgroups finished) is zeroed at creation, and the kernel's last
-    // workgroup zeroes it again on its way out, so no launch needs a memset in front of it.
+    // workgroup zeroes it again on its way out, so no launch needs a memset in front of it; a
+    // launch or a synchronisation that fails zeroes it here (reset_work).
     // The scalar cache serves the sieve faster than LDS while the geometry stream fits in it.
     int mode = c->kernel == RT_KERNEL_STREAM_SGPR || c->kernel == RT_KERNEL_STREAM_CULLED ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES)
@@ -470,7 +521,19 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         if (rc != RT_OK) return rc;
         if (on) mode = 2;
     }
-    HIP_TRY(rt_launch_stream(P, fused, record, mode, blocks, threads, c->stream));
+    P.static_spans = rt_static_spans(P, blocks, threads);
+    hipError_t e = hipSuccess;
+    if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
+        c->fail_next_launch = false;
+        (void)hipMemsetAsync(c->d_work, 0xff, RT_WORK_BYTES, c->stream);
+        e = hipErrorLaunchFailure;
+    } else {
+        e = rt_launch_stream(P, fused, record, mode, blocks, threads, c->stream);
+    }
+    if (e != hipSuccess) {
+        reset_work(c);
+        return fail(RT_E_HIP, "stream kernel launch (%d x %d): %s", blocks, threads, hipGetErrorString(e));
+    }
     c->last_blocks = blocks;
     c->last_threads = threads;
     return RT_OK;
@@ -493,7 +556,9 @@ int rt_create(int device, int width, int height, rt_context** out)
         return fail(RT_E_HIP, "no HIP device available (%s); this library has no CPU path",
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(RT_E_INVALID, "device %d out of range [0,%d)", device, n);
-    HIP_TRY(hipSetDevice(device));
+    RtDeviceGuard guard_(device);
+    if (guard_.status() != hipSuccess)
+        return fail(RT_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(guard_.status()));
     rt_context* c = new (std::nothrow) rt_context();
     if (!c) return fail(RT_E_NOMEM, "out of host memory");
     c->device = device;
@@ -526,9 +591,9 @@ int rt_create(int device, int width, int height, rt_context** out)
 int rt_destroy(rt_context* c)
 {
     if (!c) return RT_OK;
-    (void)hipSetDevice(c->device);
+    RtDeviceGuard guard_(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)free_images(c);
+    free_images(c);
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_radius) (void)hipFree(c->d_radius);
@@ -550,10 +615,8 @@ int rt_resize(rt_context* c, int width, int height)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
     if (width <= 0 || height <= 0) return fail(RT_E_INVALID, "bad image size %dx%d", width, height);
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));  // vkDeviceWaitIdle, compute_pipeline.cpp:53
-    int rc = free_images(c);
-    if (rc != RT_OK) return rc;
     return alloc_images(c, width, height);  // also unbinds caller-owned buffers
 }
 
@@ -561,7 +624,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
     if (count < 0 || (count > 0 && !aos)) return fail(RT_E_INVALID, "bad sphere buffer");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     const int cap = std::max(RT_CHUNK, (count + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK);
     HIP_TRY(hipStreamSynchronize(c->stream));  // no launch may still read the old buffers
     if (cap > c->sphere_cap) {
@@ -618,7 +681,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
 int rt_upload_materials(rt_context* c, const float* kind_param, int count)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (count == 0 || !kind_param) {  // back to the reference's single surface response
         c->have_materials = false;
@@ -728,7 +791,7 @@ int rt_get_info(rt_context* c, int* device, int* cu_count, int* blocks, int* thr
 int rt_dispatch_frames(rt_context* c, int n_frames)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     RtParams P;
     int rc = make_params(c, n_frames, &P);
     if (rc != RT_OK) return rc;
@@ -743,15 +806,19 @@ int rt_dispatch(rt_context* c) { return rt_dispatch_frames(c, 1); }
 int rt_sync(rt_context* c)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    RT_ON_DEVICE(c);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        reset_work(c);
+        return fail(RT_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    }
     return RT_OK;
 }
 
 int rt_read_color(rt_context* c, uint8_t* rgba8)
 {
     if (!c || !rgba8) return fail(RT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(rgba8, c->color, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -760,7 +827,7 @@ int rt_read_color(rt_context* c, uint8_t* rgba8)
 int rt_read_accum(rt_context* c, float* rgba32f)
 {
     if (!c || !rgba32f) return fail(RT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(rgba32f, c->accum, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -769,7 +836,7 @@ int rt_read_accum(rt_context* c, float* rgba32f)
 int rt_write_accum(rt_context* c, const float* rgba32f)
 {
     if (!c || !rgba32f) return fail(RT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(c->accum, rgba32f, (size_t)c->width * c->height * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -786,7 +853,7 @@ int rt_device_buffers(rt_context* c, void** accum_dev, void** color_dev)
 int rt_bind_buffers(rt_context* c, void* accum_dev, void* color_dev)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->accum = accum_dev ? static_cast<float4*>(accum_dev) : c->accum_own;
     c->color = color_dev ? static_cast<uint32_t*>(color_dev) : c->color_own;
@@ -796,7 +863,7 @@ int rt_bind_buffers(rt_context* c, void* accum_dev, void* color_dev)
 int rt_resolve(rt_context* c, float divisor)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     const int rows = c->height / 8;
     const int r0 = std::max(0, c->row0);
     const int r1 = (c->row1 > 0 && c->row1 < rows) ? c->row1 : rows;
@@ -809,7 +876,7 @@ int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_
                   float* light)
 {
     if (!c || !records) return fail(RT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     RtParams P;
     int rc = make_params(c, n_frames, &P);
     if (rc != RT_OK) return rc;
@@ -821,7 +888,7 @@ int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_
     P.tile_cols = (x0 + w + 7) / 8 - P.tile_col0;
     P.tile_row0 = y0 / 8;
     P.tile_rows = (y0 + h + 7) / 8 - P.tile_row0;
-    finish_params(P);
+    rt_finish_params(P);
     P.rec_x0 = x0;
     P.rec_y0 = y0;
     P.rec_w = w;
@@ -870,22 +937,22 @@ int rt_trace_crop(rt_context* c, int n_frames, int x0, int y0, int w, int h, rt_
 int rt_get_counters(rt_context* c, rt_counters* out)
 {
     if (!c || !out) return fail(RT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     static_assert(sizeof(unsigned long long) == 8, "ray counters are 64-bit");
     unsigned long long slots[RT_RAY_SLOTS * RT_RAY_SLOT_STRIDE];
     HIP_TRY(hipMemcpyAsync(slots, c->d_rays, RT_RAY_BYTES, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned long long rays = 0;
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) rays += slots[i * RT_RAY_SLOT_STRIDE];
-    int count = 0;
-    if (c->have_ubo) memcpy(&count, c->ubo + 60, 4);
+    unsigned long long tests = 0;
+    for (unsigned i = 0; i < RT_RAY_SLOTS; i++) tests += slots[i * RT_RAY_SLOT_STRIDE + 2];
 #ifdef RT_COUNT_PASSES
     unsigned long long passes = 0;
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passes += slots[i * RT_RAY_SLOT_STRIDE + 1];
     fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)rays / passes : 0.0);
 #endif
     out->rays = rays;
-    out->sphere_tests = rays * (uint64_t)std::max(0, count);
+    out->sphere_tests = tests;
     out->paths = c->paths;
     return RT_OK;
 }
@@ -893,7 +960,7 @@ int rt_get_counters(rt_context* c, rt_counters* out)
 int rt_reset_counters(rt_context* c)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipMemsetAsync(c->d_rays, 0, RT_RAY_BYTES, c->stream));
     c->paths = 0;
     return RT_OK;
@@ -902,7 +969,7 @@ int rt_reset_counters(rt_context* c)
 int rt_timer_begin(rt_context* c)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return RT_OK;
 }
@@ -910,10 +977,19 @@ int rt_timer_begin(rt_context* c)
 int rt_timer_end(rt_context* c, float* ms)
 {
     if (!c || !ms) return fail(RT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RT_OK;
+}
+
+// Test hook: the next stream-kernel launch of this context is not made; the dispatch returns
+// RT_E_HIP and finds the span counters as a kernel that died half way would have left them.
+int rt_debug_fail_next_launch(rt_context* c)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    c->fail_next_launch = true;
     return RT_OK;
 }
 
@@ -923,7 +999,7 @@ int rt_timer_end(rt_context* c, float* ms)
 int rt_debug_math(rt_context* c, int op, const float* a, const float* b, const float* cc, float* out, int n)
 {
     if (!c || !a || !b || !cc || !out || n <= 0) return fail(RT_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     float* d = nullptr;
     const size_t bytes = (size_t)n * sizeof(float);
     HIP_TRY(hipMalloc(&d, 4 * bytes));
@@ -945,7 +1021,7 @@ int rt_debug_math(rt_context* c, int op, const float* a, const float* b, const f
 int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t out[4])
 {
     if (!c || !rays || !out || n_rays <= 0) return fail(RT_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     RtParams P;
     int rc = make_params(c, 1, &P);
     if (rc != RT_OK) return rc;
@@ -971,7 +1047,7 @@ int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t 
 int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t out[3])
 {
     if (!c || !rays || !out || n_rays <= 0) return fail(RT_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
+    RT_ON_DEVICE(c);
     RtParams P;
     int rc = make_params(c, 1, &P);
     if (rc != RT_OK) return rc;

@@ -1,0 +1,57 @@
+// rt_internal.h -- what the translation units of libraytracing_amd.so share besides the C ABI:
+// the kernel launchers (rt_kernels.hip), the launch-geometry helpers (rt_api.cpp) and the
+// thread-local error message.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_params.h"
+
+// ---- rt_kernels.hip
+size_t rt_stream_lds_bytes(int n_lds, int threads);
+hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
+                            hipStream_t st);
+hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
+                                hipStream_t st);
+hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
+hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
+                             int y1, float divisor, hipStream_t st);
+hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
+                                 hipStream_t st);
+hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const float* c, float* out,
+                                int n, hipStream_t st);
+
+// ---- rt_api.cpp
+// Sets the calling thread's error message (printf style) and returns `code`.
+int rt_fail(int code, const char* fmt, ...);
+// Derived kernel arguments: call after sphere_count, n_pad, n_frames and the tile rectangle are set.
+void rt_finish_params(RtParams& P);
+// Workgroup count and size of the stream kernel on a device of `cu_count` compute units;
+// want_blocks / want_threads: 0 = choose.
+void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const RtParams& P, int* blocks,
+                        int* threads);
+// Spans every wave of a blocks x threads launch takes up front (RtParams::static_spans).
+int rt_static_spans(const RtParams& P, int blocks, int threads);
+constexpr size_t RT_LDS_PER_CU = 160 * 1024;
+
+// Makes `device` current for the lifetime of the object and puts the caller's device back after.
+class RtDeviceGuard {
+public:
+    explicit RtDeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        err_ = prev_ == device ? hipSuccess : hipSetDevice(device);
+        if (prev_ == device) prev_ = -1;  // nothing to put back
+    }
+    ~RtDeviceGuard()
+    {
+        if (prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    RtDeviceGuard(const RtDeviceGuard&) = delete;
+    RtDeviceGuard& operator=(const RtDeviceGuard&) = delete;
+    hipError_t status() const { return err_; }
+
+private:
+    int prev_ = -1;
+    hipError_t err_ = hipSuccess;
+};

@@ -27,7 +27,7 @@
 //                    LDS with wave-uniform ds_read_b128; the walk reads the LDS copy.
 #include <hip/hip_runtime.h>
 
-#include "rt_params.h"
+#include "rt_internal.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -371,15 +371,20 @@ __device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// One addition per wave, into one of RT_RAY_SLOTS counters a cache line apart (the host adds
-// them up): the waves of a launch finish together, and on a single address their additions
-// would complete one after the other.
+// One wave instruction per wave adds its rays (word 0 of a slot) and its ray-sphere tests, rays x
+// the sphere count of this dispatch (word 2), into one of RT_RAY_SLOTS slots a cache line apart
+// (the host adds them up): the waves of a launch finish together, and on a single address their
+// additions would complete one after the other.
 __device__ __forceinline__ void add_rays(const RtParams& P, unsigned nrays, unsigned slot)
 {
     unsigned long long v = nrays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(P.rays + (slot % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE, v);
+    v = __shfl(v, 0, 64);
+    const unsigned lane = threadIdx.x & 63;
+    if ((lane == 0 || lane == 2) && v != 0)
+        atomicAdd(P.rays + (slot % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + lane,
+                  lane == 0 ? v : v * (unsigned long long)P.sphere_count);
 }
 
 // ---------------------------------------------------------------- tile kernel
@@ -587,29 +592,43 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
-    // wave-uniform work span.  Spans of RT_SPAN pixels are dealt round-robin into RT_QUEUES
-    // queues, each with a counter on a cache line of its own: atomics on one address complete
-    // one at a time (~10 ns each), and with a single counter the thousands of requests of a
-    // short frame would take longer than its arithmetic.  A wave draws from the queue of its
-    // workgroup (workgroups go round-robin over the XCDs, so that is one queue per XCD) and moves
-    // on to the next queue when one runs dry.
+    // wave-uniform work span.  A wave first works through its own `P.static_spans` spans of
+    // RT_SPAN pixels, interleaved with those of the other waves (span = wave + k * waves, so every
+    // wave samples the whole image) and taken without asking anybody.  The spans after those are
+    // dealt round-robin into RT_QUEUES queues, each with a counter on a cache line of its own:
+    // atomics on one address complete one at a time (~10 ns each), and if every span of a short
+    // frame were requested that way the requests would take longer than its arithmetic.  A wave
+    // draws from the queue of its workgroup (workgroups go round-robin over the XCDs, so that is
+    // one queue per XCD) and moves on to another queue when its own runs dry.
     const uint32_t nspans = (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
-    uint32_t queue = blockIdx.x % RT_QUEUES, queues_left = RT_QUEUES;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
+    const uint32_t n_static = (unsigned long long)P.static_spans * nwaves <= nspans ? (uint32_t)P.static_spans : 0u;
+    const uint32_t dyn_base = n_static * nwaves;  // first span of the queues
+    const uint32_t dyn_n = nspans - dyn_base;
+    uint32_t static_k = 0;
+    uint32_t queue = blockIdx.x % RT_QUEUES;
     uint32_t span_cur = 0, span_end = 0;
     bool exhausted = false;
+    auto queue_len = [&](uint32_t q) -> uint32_t { return (dyn_n + RT_QUEUES - 1 - q) / RT_QUEUES; };
     // Lane 0 asks a queue for its next span; the answer is left in a vector register so that
     // nobody waits for it before it is needed.
     auto ask = [&](uint32_t q) -> uint32_t {
-        const uint32_t qcount = (nspans + RT_QUEUES - 1 - q) / RT_QUEUES;
-        unsigned* counter = P.work_counter + q * RT_QUEUE_STRIDE;
         uint32_t k = 0xffffffffu;
-        if (lane == 0) {
-            // another workgroup's queue: look first, a plain load does not line up behind atomics
-            if (queues_left == RT_QUEUES ||
-                __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qcount)
-                k = atomicAdd(counter, 1u);
-        }
+        if (lane == 0) k = atomicAdd(P.work_counter + q * RT_QUEUE_STRIDE, 1u);
         return k;
+    };
+    // The next queue after `q` that still holds spans, or RT_QUEUES when all are dry: lanes
+    // 0..RT_QUEUES-1 look at one counter each (one load for the wave, no atomics).
+    auto next_queue = [&](uint32_t q) -> uint32_t {
+        bool has = false;
+        if (lane < (int)RT_QUEUES)
+            has = __hip_atomic_load(P.work_counter + lane * RT_QUEUE_STRIDE, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) < queue_len((uint32_t)lane);
+        const unsigned long long m = __ballot(has);
+        if (m == 0ull) return RT_QUEUES;
+        const unsigned long long after = m & ~((2ull << q) - 1ull);  // queues q+1 .. : first choice
+        return (uint32_t)__builtin_ctzll(after ? after : m);
     };
     uint32_t ahead = 0xffffffffu;
     bool have_ahead = false;
@@ -639,24 +658,33 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         unsigned long long freem = __ballot(!alive);
         while (freem != 0ull && !exhausted) {
             if (span_cur == span_end) {
-                // spans q, q + RT_QUEUES, ... belong to queue q
-                const uint32_t qcount = (nspans + RT_QUEUES - 1 - queue) / RT_QUEUES;
-                const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
-                have_ahead = false;
-                if (k >= qcount) {
-                    if (--queues_left == 0) {
-                        exhausted = true;
-                        break;
+                if (static_k < n_static) {
+                    span_cur = (wave_id + static_k * nwaves) * RT_SPAN;
+                    span_end = min(span_cur + RT_SPAN, P.total_pixels);
+                    static_k++;
+                    if (prefetch && static_k == n_static) {
+                        ahead = ask(queue);  // the first request, answered while this span is traced
+                        have_ahead = true;
                     }
-                    queue = (queue + 1) % RT_QUEUES;
-                    continue;
-                }
-                span_cur = (k * RT_QUEUES + queue) * RT_SPAN;
-                span_end = min(span_cur + RT_SPAN, P.total_pixels);
-                if (prefetch) {
-                    // short spans: ask for the next one now and read the answer when this one is used up
-                    ahead = ask(queue);
-                    have_ahead = true;
+                } else {
+                    // spans dyn_base + q, dyn_base + q + RT_QUEUES, ... belong to queue q
+                    const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
+                    have_ahead = false;
+                    if (k >= queue_len(queue)) {
+                        queue = next_queue(queue);
+                        if (queue == RT_QUEUES) {
+                            exhausted = true;
+                            break;
+                        }
+                        continue;
+                    }
+                    span_cur = (dyn_base + k * RT_QUEUES + queue) * RT_SPAN;
+                    span_end = min(span_cur + RT_SPAN, P.total_pixels);
+                    if (prefetch) {
+                        // short spans: ask for the next one now and read the answer when this one is used up
+                        ahead = ask(queue);
+                        have_ahead = true;
+                    }
                 }
             }
             const uint32_t navail = span_end - span_cur;

@@ -382,6 +382,51 @@ def test_errors_are_reported(rt, default_scene):
         rt.Renderer(0, 10)
 
 
+def test_failed_launch_is_followed_by_a_correct_one(rt, default_scene):
+    """A stream-kernel launch that fails leaves the work-queue counters as they were (here: as a
+    kernel that died half way would); the dispatch must say so, and the next one must render."""
+    ubo = default_scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    with rt.Renderer(128, 72) as r:
+        r.upload_spheres(default_scene.spheres)
+        r.set_uniforms(ubo)
+        r.dispatch(1)
+        rt._native.check(rt._native.lib().rt_debug_fail_next_launch(r._h))
+        with pytest.raises(rt.RtError):
+            r.dispatch(1)
+        r.dispatch(2)  # frame 1 clears, so the earlier dispatch leaves no trace
+        acc, col, cnt = r.read_accum(), r.read_color(), r.counters()
+    cacc, ccol, crays = O.render(ubo, default_scene.spheres, 128, 72, n_frames=2)
+    assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol)
+    one, _, rays1 = O.render(ubo, default_scene.spheres, 128, 72, n_frames=1)
+    assert cnt["rays"] == rays1 + crays
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_counters_follow_the_sphere_count_of_each_dispatch(rt, default_scene, kernel):
+    """sphere_tests = sum over dispatches of rays x THAT dispatch's sphereCount."""
+    ubo = default_scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    expect = 0
+    with rt.Renderer(128, 72) as r:
+        r.set_kernel(kernel)
+        r.upload_spheres(default_scene.spheres)
+        last = 0
+        for count in (40, 7, 33, 0):
+            ubo["sphereCount"][0] = count
+            r.set_uniforms(ubo)
+            r.dispatch(2)
+            rays = r.counters()["rays"]
+            _, _, crays = O.render(ubo, default_scene.spheres, 128, 72, n_frames=2)
+            assert rays - last == crays and crays > 0
+            expect += crays * count
+            last = rays
+        cnt = r.counters()
+        assert cnt["sphere_tests"] == expect and cnt["paths"] == 4 * 2 * 128 * 72
+        r.reset_counters()
+        assert r.counters() == {"rays": 0, "sphere_tests": 0, "paths": 0}
+
+
 # ---------------------------------------------------------------- full-size properties
 
 def test_full_size_4k_stream_equals_tile(rt, rtiow_scene):
