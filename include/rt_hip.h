@@ -212,6 +212,29 @@ int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t
    dispatch after it must render correctly.  No reference counterpart. */
 int rt_debug_fail_next_launch(rt_context* ctx);
 
+/* One dispatch that allocates nothing.  No counterpart in the reference; it exists for callers
+   that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+   harnesses that forbid hipMalloc.  Same kernels and same bits as
+       rt_create + rt_upload_spheres + rt_set_uniforms + rt_set_max_depth + rt_set_profile +
+       rt_bind_buffers + rt_dispatch_frames(n_frames)
+   with the defaults of a new context (RT_KERNEL_STREAM, whole image, frame stride 1,
+   RT_CLEAR_REFERENCE), but the device memory a context would own (work-queue counters, ray
+   counters, repacked sieve geometry) is a static device array inside the library, about 100 KiB
+   per GPU, held until the process ends.  Inputs and outputs are the caller's:
+     spheres_aos32_dev  DEVICE pointer to n_spheres 32-byte spheres (includes/scene.hpp:31-36),
+                        n_spheres <= RT_STATIC_MAX_SPHERES (larger scenes are rejected with
+                        RT_E_INVALID; use a context for them); no material extension;
+     ubo80              host pointer to the 80-byte uniform block (sphereCount <= n_spheres);
+     accum_dev, color_dev  DEVICE images, width*height*16 and width*height*4 bytes;
+     rays_dev           optional DEVICE pointer: receives the number of Trace() calls of this call;
+     hip_stream         a hipStream_t (NULL = the default stream); the call is asynchronous on it.
+   It calls no hipMalloc/hipFree.  All calls on one GPU share that GPU's array: calls that
+   overlap on one GPU (different streams or threads) race and must be serialised by the caller. */
+#define RT_STATIC_MAX_SPHERES 4096
+int rt_dispatch_static(int device, void* hip_stream, const void* spheres_aos32_dev, int n_spheres,
+                       const void* ubo80, int width, int height, int n_frames, int max_depth,
+                       int profile, void* accum_dev, void* color_dev, uint64_t* rays_dev);
+
 const char* rt_last_error(void);
 
 /* -------------------------------------------------------------- scene model */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "rt_debug_sieve_audit": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),
     "rt_debug_cull_audit": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),
     "rt_debug_fail_next_launch": (C.c_int, [_P]),
+    "rt_dispatch_static": (C.c_int, [C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      _P, _P, _P]),
     "rt_last_error": (C.c_char_p, []),
     "rt_scene_load": (C.c_int, [C.c_char_p, _PP]),
     "rt_scene_parse": (C.c_int, [C.c_char_p, C.c_size_t, _PP]),
@@ -83,6 +85,8 @@ SIGNATURES = {
     "rt_scene_reset_frame_count": (C.c_int, [_P]),
     "rt_scene_generate": (C.c_int, [C.c_int, C.c_int, C.c_uint32, _PP]),
 }
+
+STATIC_MAX_SPHERES = 4096  # RT_STATIC_MAX_SPHERES of include/rt_hip.h
 
 _lib = None
 
