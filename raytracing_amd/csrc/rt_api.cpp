@@ -409,25 +409,6 @@ void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const R
     *threads = t;
 }
 
-// Spans a wave of the stream kernel takes without asking (RtParams::static_spans).  A dispatch
-// whose spans are short (few frames, few spheres) would otherwise spend longer on its span
-// requests than on tracing: one 1080p frame is 32 400 spans, and requests to one counter
-// complete about 11 ns apart.  Such a dispatch hands every wave 7/8 of its fair share up front,
-// interleaved over the image, and leaves the rest in the queues to even out the finish.  A
-// dispatch with long spans keeps them all in the queues: its requests cost nothing next to the
-// tracing, and the last span a wave holds is the kernel's tail.
-int rt_static_spans(const RtParams& P, int blocks, int threads)
-{
-    static const int forced = [] {
-        const char* e = getenv("RT_DEBUG_STATIC_EIGHTHS");  // development knob: 0..8 eighths of the fair share
-        return e ? std::max(0, std::min(8, atoi(e))) : -1;
-    }();
-    const int eighths = forced >= 0 ? forced : (P.prefetch ? 7 : 0);
-    const unsigned nspans = (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
-    const unsigned waves = (unsigned)blocks * (unsigned)(threads / 64);
-    return (int)((unsigned long long)nspans * eighths / 8 / std::max(1u, waves));
-}
-
 namespace {
 
 // Build and upload the sorted copy of the first `count` spheres unless the device already holds it.
@@ -521,7 +502,6 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         if (rc != RT_OK) return rc;
         if (on) mode = 2;
     }
-    P.static_spans = rt_static_spans(P, blocks, threads);
     hipError_t e = hipSuccess;
     if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
         c->fail_next_launch = false;
@@ -950,6 +930,25 @@ int rt_get_counters(rt_context* c, rt_counters* out)
     unsigned long long passes = 0;
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passes += slots[i * RT_RAY_SLOT_STRIDE + 1];
     fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)rays / passes : 0.0);
+#endif
+#ifdef RT_PHASE_TIMERS
+    {
+        unsigned long long t[5] = {0, 0, 0, 0, 0};
+        for (unsigned i = 0; i < RT_RAY_SLOTS; i++)
+            for (int k = 0; k < 5; k++) t[k] += slots[i * RT_RAY_SLOT_STRIDE + 3 + k];
+        fprintf(stderr, "wave cycles: refill %llu sieve %llu walk %llu shade %llu; iterations %llu; per iteration %.0f %.0f %.0f %.0f\n",
+                t[0], t[1], t[2], t[3], t[4], (double)t[0] / t[4], (double)t[1] / t[4], (double)t[2] / t[4],
+                (double)t[3] / t[4]);
+        unsigned long long w[6] = {0, 0, 0, 0, 0, 0};
+        for (unsigned i = 0; i < RT_RAY_SLOTS; i++) {
+            const unsigned long long* q = slots + i * RT_RAY_SLOT_STRIDE + 8;
+            w[0] += q[0]; w[1] += q[1]; w[2] = std::max(w[2], q[2]); w[3] = std::max(w[3], q[3]);
+            w[4] = std::max(w[4], q[4]); w[5] += q[5];
+        }
+        const double nw = (double)std::max(1ull, w[5]);
+        fprintf(stderr, "wave lifetime (us): mean %.1f, shortest %.1f, longest %.1f; after the queues ran dry: mean %.1f, longest %.1f\n",
+                w[0] * 0.01 / nw, ~w[3] * 0.01, w[2] * 0.01, w[1] * 0.01 / nw, w[4] * 0.01);
+    }
 #endif
     out->rays = rays;
     out->sphere_tests = tests;

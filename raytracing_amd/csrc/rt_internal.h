@@ -30,8 +30,6 @@ void rt_finish_params(RtParams& P);
 // want_blocks / want_threads: 0 = choose.
 void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const RtParams& P, int* blocks,
                         int* threads);
-// Spans every wave of a blocks x threads launch takes up front (RtParams::static_spans).
-int rt_static_spans(const RtParams& P, int blocks, int threads);
 constexpr size_t RT_LDS_PER_CU = 160 * 1024;
 
 // Makes `device` current for the lifetime of the object and puts the caller's device back after.

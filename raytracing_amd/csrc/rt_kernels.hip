@@ -27,6 +27,8 @@
 //                    LDS with wave-uniform ds_read_b128; the walk reads the LDS copy.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rt_internal.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -592,25 +594,16 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
-    // wave-uniform work span.  A wave first works through its own `P.static_spans` spans of
-    // RT_SPAN pixels, interleaved with those of the other waves (span = wave + k * waves, so every
-    // wave samples the whole image) and taken without asking anybody.  The spans after those are
-    // dealt round-robin into RT_QUEUES queues, each with a counter on a cache line of its own:
-    // atomics on one address complete one at a time (~10 ns each), and if every span of a short
-    // frame were requested that way the requests would take longer than its arithmetic.  A wave
-    // draws from the queue of its workgroup (workgroups go round-robin over the XCDs, so that is
-    // one queue per XCD) and moves on to another queue when its own runs dry.
+    // wave-uniform work span.  Spans of RT_SPAN pixels are dealt round-robin into RT_QUEUES
+    // queues, each with a counter on a cache line of its own: atomics on one address complete one
+    // at a time (~10 ns each).  A wave draws from the queue of its workgroup (workgroups go
+    // round-robin over the XCDs, so that is one queue per XCD) and moves on to another queue when
+    // its own runs dry.
     const uint32_t nspans = (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
-    const uint32_t n_static = (unsigned long long)P.static_spans * nwaves <= nspans ? (uint32_t)P.static_spans : 0u;
-    const uint32_t dyn_base = n_static * nwaves;  // first span of the queues
-    const uint32_t dyn_n = nspans - dyn_base;
-    uint32_t static_k = 0;
     uint32_t queue = blockIdx.x % RT_QUEUES;
     uint32_t span_cur = 0, span_end = 0;
     bool exhausted = false;
-    auto queue_len = [&](uint32_t q) -> uint32_t { return (dyn_n + RT_QUEUES - 1 - q) / RT_QUEUES; };
+    auto queue_len = [&](uint32_t q) -> uint32_t { return (nspans + RT_QUEUES - 1 - q) / RT_QUEUES; };
     // Lane 0 asks a queue for its next span; the answer is left in a vector register so that
     // nobody waits for it before it is needed.
     auto ask = [&](uint32_t q) -> uint32_t {
@@ -653,38 +646,44 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
     p.ox = p.oy = p.oz = 0.f; p.dx = p.dy = p.dz = 0.f;
     p.cr = p.cg = p.cb = 0.f; p.lr = p.lg = p.lb = 0.f; p.bounce = 0;
 
+#ifdef RT_PHASE_TIMERS
+    // experiment: shader-clock cycles this wave spends in each phase of its loop, added to words
+    // 3..7 of its counter slot (refill, sieve, walk, shade, iterations)
+    unsigned long long t_refill = 0, t_sieve = 0, t_walk = 0, t_shade = 0, n_iter = 0;
+    unsigned long long t_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock
+    unsigned long long rt_exhausted = 0;
+#define RT_MARK(acc)                                                  \
+    {                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        acc += t_ - t_mark;                                           \
+        t_mark = t_;                                                  \
+    }
+#else
+#define RT_MARK(acc)
+#endif
     for (;;) {
         // ---- refill: free lanes take the next pixels of the wave's span
         unsigned long long freem = __ballot(!alive);
         while (freem != 0ull && !exhausted) {
             if (span_cur == span_end) {
-                if (static_k < n_static) {
-                    span_cur = (wave_id + static_k * nwaves) * RT_SPAN;
-                    span_end = min(span_cur + RT_SPAN, P.total_pixels);
-                    static_k++;
-                    if (prefetch && static_k == n_static) {
-                        ahead = ask(queue);  // the first request, answered while this span is traced
-                        have_ahead = true;
+                // spans q, q + RT_QUEUES, ... belong to queue q
+                const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
+                have_ahead = false;
+                if (k >= queue_len(queue)) {
+                    queue = next_queue(queue);
+                    if (queue == RT_QUEUES) {
+                        exhausted = true;
+                        break;
                     }
-                } else {
-                    // spans dyn_base + q, dyn_base + q + RT_QUEUES, ... belong to queue q
-                    const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
-                    have_ahead = false;
-                    if (k >= queue_len(queue)) {
-                        queue = next_queue(queue);
-                        if (queue == RT_QUEUES) {
-                            exhausted = true;
-                            break;
-                        }
-                        continue;
-                    }
-                    span_cur = (dyn_base + k * RT_QUEUES + queue) * RT_SPAN;
-                    span_end = min(span_cur + RT_SPAN, P.total_pixels);
-                    if (prefetch) {
-                        // short spans: ask for the next one now and read the answer when this one is used up
-                        ahead = ask(queue);
-                        have_ahead = true;
-                    }
+                    continue;
+                }
+                span_cur = (k * RT_QUEUES + queue) * RT_SPAN;
+                span_end = min(span_cur + RT_SPAN, P.total_pixels);
+                if (prefetch) {
+                    // short spans: ask for the next one now and read the answer when this one is used up
+                    ahead = ask(queue);
+                    have_ahead = true;
                 }
             }
             const uint32_t navail = span_end - span_cur;
@@ -709,6 +708,11 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
             freem = __ballot(!alive);
         }
         if (__ballot(alive) == 0ull) break;
+        RT_MARK(t_refill)
+#ifdef RT_PHASE_TIMERS
+        n_iter++;
+        if (exhausted && rt_exhausted == 0) rt_exhausted = __builtin_amdgcn_s_memrealtime();
+#endif
 
         // ---- a lane at the start of a path generates its camera ray
         if (start) {
@@ -786,6 +790,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                     summary = (summary << 1) | (cand != 0u ? 1u : 0u);
                 }
                 summary <<= (32 - nsg);
+                RT_MARK(t_sieve)
                 // walk: every lane visits its own candidates in increasing sphere index
                 uint32_t cur = 0;
                 int curbase = 0;
@@ -814,6 +819,7 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                         }
                     }
                 }
+                RT_MARK(t_walk)
             }
         }
 
@@ -838,7 +844,30 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                 }
             }
         }
+        RT_MARK(t_shade)
     }
+#ifdef RT_PHASE_TIMERS
+    if (lane == 0) {
+        unsigned long long* slot =
+            P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE;
+        atomicAdd(slot + 3, t_refill);
+        atomicAdd(slot + 4, t_sieve);
+        atomicAdd(slot + 5, t_walk);
+        atomicAdd(slot + 6, t_shade);
+        atomicAdd(slot + 7, n_iter);
+        // wall-clock marks in the slot's words 8..: sum of wave lifetimes, sum of the time waves
+        // spend after the queues ran dry, longest and shortest (stored inverted) lifetime,
+        // longest time after the queues ran dry
+        const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+        if (rt_exhausted == 0) rt_exhausted = rt_end;
+        atomicAdd(slot + 8, rt_end - rt_start);
+        atomicAdd(slot + 9, rt_end - rt_exhausted);
+        atomicMax(slot + 10, rt_end - rt_start);
+        atomicMax(slot + 11, ~(rt_end - rt_start));
+        atomicMax(slot + 12, rt_end - rt_exhausted);
+        atomicAdd(slot + 13, 1ull);
+    }
+#endif
     if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave);
 #ifdef RT_COUNT_PASSES
     if (lane == 0)
@@ -1021,7 +1050,12 @@ size_t rt_stream_lds_bytes(int n_lds, int threads)
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
-    const size_t lds = rt_stream_lds_bytes(P.n_lds, threads);
+    size_t lds = rt_stream_lds_bytes(P.n_lds, threads);
+    static const size_t pad = [] {
+        const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    lds += pad;
     if (mode == 2) {
         if (record)
             return fused ? launch_stream<true, true, 2>(P, blocks, threads, lds, st)

@@ -63,8 +63,6 @@ struct RtParams {
     unsigned last_chunk_valid; // bit (31-n) set when sphere n of the last chunk is < sphere_count
     int last_chunk_count;      // spheres in the last chunk (1..32; 0 for an empty scene)
     int prefetch;              // stream kernel: waves ask for their next span one span ahead
-    int static_spans;          // stream kernel: spans every wave takes without asking, before it turns
-                               // to the queues (static_spans * waves <= spans); set at launch
     int tile_row0;     // first row of 8x8 tiles rendered
     int tile_rows;     // number of tile rows rendered
     unsigned total_pixels;  // tile_cols * tile_rows * 64

@@ -188,7 +188,6 @@ extern "C" int rt_dispatch_static(int device, void* hip_stream, const void* sphe
         rt_stream_geometry(dev.cu_count, 0, 0, P, &blocks, &threads);
         if (rt_stream_lds_bytes(P.n_lds, threads) > RT_LDS_PER_CU)
             return rt_fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
-        P.static_spans = rt_static_spans(P, blocks, threads);
         const int mode = P.n_pad <= RT_MAX_SGPR_SPHERES ? 1 : 0;  // as RT_KERNEL_STREAM chooses
         STATIC_TRY(rt_launch_stream(P, profile == RT_PROFILE_FUSED, false, mode, blocks, threads, st));
     }

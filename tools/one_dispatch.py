@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few timed dispatches of one workload (development aid for counter collection):
-   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 tools/one_dispatch.py [scene W H frames depth kernel reps]
+   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 tools/one_dispatch.py [scene W H frames depth kernel reps sphereCount frame0]
 scene: rtiow | default | cubeN.  The first dispatch is a warm-up; the counters printed are those
 of the `reps` timed dispatches."""
 import os
@@ -20,6 +20,8 @@ frames = int(a[3]) if len(a) > 3 else 8
 depth = int(a[4]) if len(a) > 4 else 50
 kernel = int(a[5]) if len(a) > 5 else 0
 reps = int(a[6]) if len(a) > 6 else 1
+count = int(a[7]) if len(a) > 7 else -1   # override ubo.sphereCount
+frame0 = int(a[8]) if len(a) > 8 else 1   # ubo.frameCount of the first frame (1 clears: no accumulation read)
 if name == "rtiow":
     scene = rt.Scene.generate(rt.KIND_RTIOW, 0, 7)
 elif name == "default":
@@ -29,7 +31,12 @@ else:
 with rt.Renderer(w, h) as r:
     r.set_kernel(kernel)
     r.set_max_depth(depth)
-    r.set_scene(scene, frame_count=1)
+    r.set_scene(scene, frame_count=frame0)
+    if count >= 0:
+        ubo = scene.camera.copy()
+        ubo["sphereCount"][0] = count
+        ubo["frameCount"][0] = frame0
+        r.set_uniforms(ubo)
     r.dispatch(frames)
     r.sync()
     r.reset_counters()
