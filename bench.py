@@ -1,93 +1,128 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: Mrays/s at 4K on the ~500-sphere RTIOW-layout scene.
+"""bench.py -- the benchmark contract of this repository.
 
-One "step" is one dispatch of --frames-per-step frames (samples per pixel) over the whole
-3840x2160 image; one ray is one Trace() call of the shader (primary or bounce segment),
-counted inside the kernel.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run): samples are split by
-frame number -- rank g of G renders frames g+1, g+1+G, ... with the unchanged RNG formula,
-so the union of samples is the single-GPU sample set -- each rank accumulates locally and one
-RCCL sum-reduce of the float4 accumulation image to rank 0 ends the job (inside the timed
-region).  Scaling is weak: every rank renders `steps * frames_per_step` frames.
+Workloads (one per configuration the baseline names; the default is the one the headline metric
+is quoted on):
 
-Output: one JSON line on rank 0.  `roofline` prices the dominant kernel against the FP32
-vector peak (the kernel has no matrix contraction, so the bound is VALU, not MFMA/HBM);
-`cpu_baseline` is the CPU oracle (a port of the shader, not the reference binary) on the
-host cores, on a bounded sample of the same workload.
+  rtiow4k         RTIOW-layout scene (484 spheres), 3840x2160, depth 50, 8 frames (spp) per step
+  default720p_d8  the reference's default scene (40 traced spheres), 1280x720, depth 8, 64 frames per step
+  default1080p    the same scene, 1920x1080, depth 50, 64 frames per step (16 steps = 1024 spp)
+  stress4096      4096 random spheres, 3840x2160, depth 50, 2 frames per step
+  interactive     default scene, 1920x1080, ONE frame per step with scripted camera motion and
+                  accumulation resets; value = ms per displayed frame
+
+One "step" is one dispatch of the path-trace kernel over the whole image; one ray is one
+Trace() call of the shader (primary or bounce segment), counted inside the kernel.
+
+Multi-GPU (one process per GPU; `--gpus N` without a launcher spawns the N ranks itself, under
+torch.distributed.run the ranks come from the environment).  The throughput workloads split
+SAMPLES: rank g of G renders frames g+1, g+1+G, ... with the unchanged RNG formula, accumulates
+locally, and one RCCL sum-reduce of the float4 accumulation image to rank 0 ends the job, inside
+the timed region (weak scaling: every rank renders steps x frames-per-step frames).  The
+interactive workload splits SCREEN TILES: every rank traces a band of tile rows of every frame
+and rank 0 gathers the rgba8 bands, the exchange of a frame overlapping the tracing of the next
+(strong scaling).
+
+Output: one JSON line on rank 0.  `roofline` prices the path-trace kernel against the FP32
+vector peak (the path has no matrix contraction) and, beside it, against HBM; `cpu_baseline`
+is the CPU oracle (a port of the shader, not the reference binary) on the host cores, on a
+bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT = 3840, 2160
-SCENE_SEED = 7
-FLOP_PER_TEST = 21          # algorithmic FP32 flop per ray-sphere test (a hoisted)
-PEAK_FP32_TFLOPS = 157.3    # MI355X FP32 vector peak
+FLOP_PER_TEST = 21             # algorithmic FP32 flop per ray-sphere test (a hoisted)
+PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak
+PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
 BYTES_PER_PIXEL_DISPATCH = 36  # float4 read + float4 write + rgba8 write
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+WORKLOADS = {
+    "rtiow4k": dict(scene="rtiow", size=(3840, 2160), depth=50, fps=8, steps=8, warmup=2,
+                    metric="Mrays/sec (whole node) @4K ~500 spheres"),
+    "default720p_d8": dict(scene="default", size=(1280, 720), depth=8, fps=64, steps=8, warmup=2,
+                           metric="Mrays/sec (whole node), default scene 1280x720, depth 8"),
+    "default1080p": dict(scene="default", size=(1920, 1080), depth=50, fps=64, steps=16, warmup=2,
+                         metric="Mrays/sec (whole node), default scene 1080p, 1024 spp"),
+    "stress4096": dict(scene="cube4096", size=(3840, 2160), depth=50, fps=2, steps=6, warmup=2,
+                       metric="Mrays/sec (whole node), 4096-sphere stress scene"),
+    "interactive": dict(scene="default", size=(1920, 1080), depth=50, fps=1, steps=400, warmup=40,
+                        metric="ms/frame 1080p interactive"),
+}
 
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=8)
-    p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--frames-per-step", type=int, default=8)
+    p.add_argument("--steps", type=int, default=None)
+    p.add_argument("--warmup", type=int, default=None)
+    p.add_argument("--workload", choices=list(WORKLOADS), default="rtiow4k")
+    p.add_argument("--frames-per-step", type=int, default=None)
     p.add_argument("--profile", choices=["strict", "fused"], default="strict")
     p.add_argument("--kernel", choices=["stream", "tile", "culled"], default="stream",
-                   help="stream: the brute-force kernel the metric is quoted on; culled: the same kernel over a "
+                   help="stream: the brute-force kernel the metrics are quoted on; culled: the same kernel over a "
                         "spatially sorted sphere list, skipping groups no ray of a wave can touch (same image)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
-    p.add_argument("--max-depth", type=int, default=50)
-    p.add_argument("--workload", choices=["rtiow4k", "interactive"], default="rtiow4k",
-                   help="rtiow4k: the headline metric; interactive: 1080p, 1 frame per dispatch, moving camera, "
-                        "screen tiles split across GPUs, ms/frame")
+    p.add_argument("--max-depth", type=int, default=None)
     p.add_argument("--materials", action="store_true",
                    help="rtiow4k with the material extension (lambertian/metal/dielectric per sphere) switched on; "
                         "the headline line is quoted without it (the reference has one surface response)")
-    return p.parse_args()
+    a = p.parse_args()
+    w = WORKLOADS[a.workload]
+    a.steps = w["steps"] if a.steps is None else a.steps
+    a.warmup = w["warmup"] if a.warmup is None else a.warmup
+    a.frames_per_step = w["fps"] if a.frames_per_step is None else a.frames_per_step
+    a.max_depth = w["depth"] if a.max_depth is None else a.max_depth
+    if a.workload == "interactive":
+        a.frames_per_step = 1
+    return a
 
 
-def cpu_baseline(scene, profile, max_depth, seconds):
-    """The oracle, multithreaded over tile rows, on whole 4K frames until `seconds` have passed."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import oracle as O
+# ------------------------------------------------------------------ launching the ranks
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as child processes (this
+    process has made no GPU call yet) and return the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max((abs(c) for c in codes), default=0)
+
+
+# ------------------------------------------------------------------ scenes and the CPU leg
+
+def make_scene(rt, name, materials=False):
+    if name == "rtiow":
+        return rt.Scene.generate(rt.KIND_RTIOW_MATERIALS if materials else rt.KIND_RTIOW, 0, 7), "rtiow-layout scene seed 7"
+    if name == "default":
+        return rt.Scene.default(), "default scene of the reference (40 traced spheres)"
+    n = int(name.replace("cube", ""))
+    return rt.Scene.generate(rt.KIND_CUBE, n, 3), f"stress scene seed 3 ({n} random spheres)"
+
+
+def host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
-    ubo = scene.camera.copy()
-    acc = None
-    rays = 0
-    frames = 0
-    t0 = time.perf_counter()
-    while True:
-        ubo["frameCount"][0] = frames + 1
-        mats = scene.materials
-        acc, _, r = O.render(ubo, scene.spheres, WIDTH, HEIGHT, max_depth=max_depth, profile=profile,
-                             n_frames=1, threads=cores, accum=acc, materials=mats if mats[:, 0].any() else None)
-        rays += r
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or frames >= 64:
-            break
-    return {
-        "value": rays / dt / 1e6,
-        "unit": "Mrays/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{frames} whole frame(s) of the same {WIDTH}x{HEIGHT} scene, depth {max_depth}, "
-                  f"{rays} rays in {dt:.1f} s (CPU oracle, {'fused' if profile else 'strict'} profile); "
-                  + lavapipe_probe(),
-    }
+    return max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
 
 
 def lavapipe_probe():
@@ -106,78 +141,293 @@ def lavapipe_probe():
     return "lavapipe baseline not possible here: " + ", ".join(missing) + " not found"
 
 
-def interactive(args, rank, world, device, backend):
-    """1080p, one frame per dispatch, the default scene with scripted camera impulses fed through
-    Scene::update so that accumulation resets on a known schedule; every rank renders a band of
-    tile rows and rank 0 gathers the rgba8 bands each frame.  A step is one displayed frame."""
-    import torch
-    import torch.distributed as dist
+def cpu_baseline(scene, size, profile, max_depth, seconds, interactive_frames=None):
+    """The oracle, multithreaded over tile rows, on whole frames of the same workload until
+    `seconds` have passed (at least one frame).  interactive_frames: the uniform blocks of the
+    interactive workload's first frames, rendered one frame per call as the GPU does."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
 
-    import raytracing_amd as rt
-    from raytracing_amd.multi_gpu import TileSplit
+    w, h = size
+    cores = host_cores()
+    mats = scene.materials
+    mats = mats if len(mats) and mats[:, 0].any() else None
+    ubo = scene.camera.copy()
+    acc, rays, frames = None, 0, 0
+    t0 = time.perf_counter()
+    while True:
+        if interactive_frames is not None:
+            ubo = interactive_frames[frames]
+        else:
+            ubo["frameCount"][0] = frames + 1
+        acc, _, r = O.render(ubo, scene.spheres, w, h, max_depth=max_depth, profile=profile, n_frames=1, threads=cores,
+                             accum=acc, materials=mats)
+        rays += r
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or frames >= 64 or (interactive_frames is not None and frames >= len(interactive_frames)):
+            break
+    sample = (f"{frames} whole frame(s) of the same {w}x{h} workload, depth {max_depth}, {rays} rays in {dt:.1f} s "
+              f"(CPU oracle, {'fused' if profile else 'strict'} profile); " + lavapipe_probe())
+    if interactive_frames is not None:
+        return {"value": dt / frames * 1e3, "unit": "ms/frame", "cores": cores, "kind": "port", "sample": sample}
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample}
 
-    w, h = 1920, 1080
-    scene = rt.Scene.default()
-    tiles = TileSplit(rank, world, h)
-    color = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+
+# ------------------------------------------------------------------ roofline
+
+def pmc_record(key):
+    """Counter-derived figures of this workload from the committed rocprofv3 passes (they cannot be
+    collected inside a timed run): HBM traffic per launch, VALU busy share, clock."""
+    try:
+        return json.load(open(PMC_FILE)).get(key)
+    except Exception:
+        return None
+
+
+def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key):
+    """Algorithmic FP32 work and HBM bytes of the average launch against the two roofs."""
+    launch_ms = kernel_ms / max(1, launches)
+    achieved = tests / max(1, launches) * FLOP_PER_TEST / (launch_ms * 1e-3) / 1e12
+    hbm = pixels_per_launch * BYTES_PER_PIXEL_DISPATCH / (launch_ms * 1e-3) / 1e9
+    pmc = pmc_record(pmc_key) or {}
+    out = {
+        "bound": "valu",
+        "bound_detail": "FP32 vector ALU: the path has no matrix contraction, so MFMA does not bound it (the FP32 "
+                        "vector peak equals the dense FP32 MFMA peak, 157.3 TFLOP/s); the HBM roof is reported beside it",
+        "achieved": achieved,
+        "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP32_TFLOPS,
+        "flop_per_test": FLOP_PER_TEST,
+        "kernel_ms_per_launch": launch_ms,
+        "launches": launches,
+        "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBPS,
+                "bytes_per_pixel_per_launch": BYTES_PER_PIXEL_DISPATCH},
+        "traffic": pmc.get("traffic_bytes_per_launch"),
+        "traffic_source": (f"profiles/{os.path.basename(PMC_FILE)}[{pmc_key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                           "passes of this command, FETCH_SIZE doubled (gfx950), collected separately, not in this run")
+                          if pmc.get("traffic_bytes_per_launch") is not None else None,
+    }
+    for k in ("valu_busy", "executed_flop_frac", "clock_ghz", "valu_insts_per_launch"):
+        if k in pmc:
+            out[k] = pmc[k]
+    if args.kernel == "culled":
+        # whole groups of spheres are skipped: rays x sphereCount counts tests that were never made
+        out["achieved"] = out["frac"] = None
+        out["note"] = (f"culled kernel: {achieved:.1f} TFLOP/s would be the brute-force-equivalent rate (rays x "
+                       "sphereCount x 21 flop), not work this kernel executes")
+    return out
+
+
+# ------------------------------------------------------------------ the two kinds of workload
+
+def throughput(args, rank, world, device, backend, torch, dist, rt):
+    from raytracing_amd.multi_gpu import SampleSplit
+
+    wl = WORKLOADS[args.workload]
+    w, h = wl["size"]
+    scene, scene_text = make_scene(rt, wl["scene"], args.materials)
+    profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
+    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED}.get(args.kernel, rt.KERNEL_STREAM)
+    fps = args.frames_per_step
+
+    split = SampleSplit(rank, world)
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    color = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     r = rt.Renderer(w, h, device=device)
     r.bind_buffers(accum.data_ptr(), color.data_ptr())
-    r.set_profile(rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT)
+    r.set_profile(profile)
+    r.set_kernel(kernel)
+    r.set_max_depth(args.max_depth)
+    r.set_scene(scene)
+
+    def run_steps(n_steps):
+        # every pass starts over at frame 1, so warm-up and timed steps do identical work
+        for s in range(n_steps):
+            split.dispatch(r, scene, step=s, frames_per_step=fps, timed=True)
+
+    def finish(total_steps):
+        """The exchange step: sum the per-rank accumulation images on rank 0 and resolve."""
+        r.sync()
+        split.reduce(accum, dst=0)
+        if rank == 0:
+            torch.cuda.current_stream().synchronize()
+            r.resolve(split.divisor(total_steps, fps))
+
+    run_steps(args.warmup)
+    finish(args.warmup)
+    r.timed_total()
+    r.reset_counters()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    finish(args.steps)
+    r.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms, launches = r.timed_total()
+    cnt = r.counters()
+    stats = torch.tensor([elapsed, float(cnt["rays"])], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_rays = float(stats[1])
+
+    if rank == 0:
+        info = r.info()
+        line = {
+            "metric": wl["metric"],
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {scene_text}, {scene.sphere_count} spheres traced, {w}x{h}, "
+                            f"{fps} frames (spp) per step per GPU, max depth {args.max_depth}, "
+                            f"float profile {args.profile}, kernel {args.kernel}"
+                            + (", material extension on" if args.materials else ""),
+                "parallelism": f"samples split by frame number over {world} GPU(s), one RCCL sum-reduce at the end",
+                "launch": f"{info['blocks']} x {info['threads']}",
+            },
+            "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
+            "roofline": roofline(args, cnt["sphere_tests"], launches, kernel_ms, (w // 8 * 8) * (h // 8 * 8),
+                                 f"{args.workload}_{args.kernel}_{args.profile}"),
+        }
+        if args.cpu_seconds > 0 and world == 1:  # the CPU leg runs at N=1 only
+            line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    r.close()
+
+
+def interactive_ubos(rt, n):
+    """The uniform blocks of the interactive workload's first n frames: a key tap every 40 frames
+    (one impulse along the view direction, src/application.cpp:44-47) fed through Scene::update at
+    dt = 1/60 s, so the accumulation resets (frameCount = 1) while the camera moves."""
+    scene = rt.Scene.default()
+    fwd = scene.camera["camera_forward"][0].copy()
+    out = []
+    for i in range(n):
+        if i % 40 == 0:
+            scene.add_acceleration(*(fwd * 100.0).tolist())
+        scene.update(1.0 / 60.0)
+        out.append(scene.camera.copy())
+    return scene, out
+
+
+def interactive(args, rank, world, device, backend, torch, dist, rt):
+    from raytracing_amd.multi_gpu import InteractiveLoop, TileSplit
+
+    wl = WORKLOADS["interactive"]
+    w, h = wl["size"]
+    profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
+    scene, ubos = interactive_ubos(rt, args.warmup + args.steps)
+    tiles = TileSplit(rank, world, h)
+    colors = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(2)]
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r = rt.Renderer(w, h, device=device)
+    r.set_profile(profile)
     r.set_max_depth(args.max_depth)
     r.upload_spheres(scene.spheres)
     tiles.apply(r)
-    fwd = scene.camera["camera_forward"][0].copy()
+    staged = world > 1 and backend != "nccl"  # gloo rehearsal: the bands travel through host memory
+    hosts = [c.cpu() for c in colors] if staged else None
 
-    def frame(i):
-        if i % 40 == 0:  # a key tap: one impulse along the view direction (src/application.cpp:44-47)
-            scene.add_acceleration(*(fwd * 100.0).tolist())
-        scene.update(1.0 / 60.0)
-        r.set_uniforms(scene.camera)
-        r.dispatch(1)
-        r.sync()
-        stage = color.cpu() if (world > 1 and backend != "nccl") else color
-        tiles.gather(stage, dst=0)
+    def image_of(k):
+        if staged and tiles.rank != 0:
+            hosts[k].copy_(colors[k])
+        return hosts[k] if staged else colors[k]
 
+    loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers(accum.data_ptr(), colors[k].data_ptr()), image_of,
+                           dispatch=lambda: r.dispatch_timed(1))
     for i in range(args.warmup):
-        frame(i)
+        loop.frame(ubos[i])
+    loop.finish()
+    r.timed_total()
     r.reset_counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        frame(args.warmup + i)
+        loop.frame(ubos[args.warmup + i])
+    loop.finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+
+    kernel_ms, launches = r.timed_total()
+    cnt = r.counters()
+    band_rows = (tiles.rows[1] - tiles.rows[0]) * 8
+    stats = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["sphere_tests"]), kernel_ms],
+                         dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms = float(tmax[0]), float(tmax[3])
     if rank == 0:
-        print(json.dumps({
-            "metric": "ms/frame 1080p interactive", "value": float(t[0]) / args.steps * 1e3, "unit": "ms",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t[0]) / args.steps * 1e3,
-            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "default scene (40 spheres), 1920x1080, 1 frame per dispatch, camera impulse every "
-                                   "40 frames, host sync + band gather every frame",
-                       "parallelism": f"bands of 8x8-tile rows over {world} GPU(s), rgba8 bands gathered to rank 0"},
-        }), flush=True)
+        info = r.info()
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": wl["metric"], "value": ms, "unit": "ms", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"interactive: default scene (40 traced spheres), {w}x{h}, 1 frame per dispatch, max depth "
+                            f"{args.max_depth}, float profile {args.profile}, camera impulse every 40 frames through "
+                            "Scene::update (accumulation resets while it moves), uniforms set and dispatch issued per frame",
+                "parallelism": f"bands of 8x8-tile rows over {world} GPU(s); rgba8 bands of frame f gathered to rank 0 "
+                               "while frame f+1 is traced (two colour images)",
+                "launch": f"{info['blocks']} x {info['threads']}",
+            },
+            "rays_per_second": float(stats[1]) / elapsed,
+            "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
+            # the slowest rank's kernel time over its launches; tests and pixels of that band
+            "roofline": roofline(args, cnt["sphere_tests"], launches, kernel_ms, (w // 8 * 8) * band_rows,
+                                 f"interactive_{args.kernel}_{args.profile}"),
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds,
+                                                interactive_frames=ubos[args.warmup:])
+        print(json.dumps(line), flush=True)
     r.close()
 
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); "
+                         "they must agree")
 
-    import torch
+    import torch  # before the HIP library: both then share PyTorch's copy of the HIP runtime
     import torch.distributed as dist
 
     import raytracing_amd as rt
-    from raytracing_amd.multi_gpu import SampleSplit
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
@@ -192,126 +442,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
-
-    if args.workload == "interactive":
-        interactive(args, rank, world, device, backend)
+    try:
+        if args.workload == "interactive":
+            interactive(args, rank, world, device, backend, torch, dist, rt)
+        else:
+            throughput(args, rank, world, device, backend, torch, dist, rt)
+    finally:
         if world > 1:
             dist.destroy_process_group()
-        return
-
-    scene = rt.Scene.generate(rt.KIND_RTIOW_MATERIALS if args.materials else rt.KIND_RTIOW, 0, SCENE_SEED)
-    profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
-    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED}.get(args.kernel, rt.KERNEL_STREAM)
-    fps = args.frames_per_step
-
-    split = SampleSplit(rank, world)
-    accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device="cuda")
-    color = torch.zeros((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
-    r = rt.Renderer(WIDTH, HEIGHT, device=device)
-    r.bind_buffers(accum.data_ptr(), color.data_ptr())
-    r.set_profile(profile)
-    r.set_kernel(kernel)
-    r.set_max_depth(args.max_depth)
-    r.set_scene(scene)
-
-    def run_steps(n_steps):
-        # every pass starts over at frame 1, so warm-up and timed steps do identical work
-        for s in range(n_steps):
-            split.dispatch(r, scene, step=s, frames_per_step=fps)
-
-    def finish(total_steps):
-        """The exchange step: sum the per-rank accumulation images on rank 0 and resolve."""
-        r.sync()
-        split.reduce(accum, dst=0)
-        if rank == 0:
-            torch.cuda.current_stream().synchronize()
-            r.resolve(split.divisor(total_steps, fps))
-
-    run_steps(args.warmup)
-    finish(args.warmup)
-    r.sync()
-    r.reset_counters()
-
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    r.timer_begin()
-    run_steps(args.steps)
-    kernel_ms = r.timer_end()
-    finish(args.steps)
-    r.sync()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    cnt = r.counters()
-    stats = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["sphere_tests"])], dtype=torch.float64,
-                         device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        tmax = stats.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-    total_rays = float(stats[1])
-
-    if rank == 0:
-        launch_ms = kernel_ms / args.steps
-        tests_per_launch = cnt["sphere_tests"] / args.steps
-        achieved = tests_per_launch * FLOP_PER_TEST / (launch_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(f"{args.kernel}_{args.profile}_fps{fps}")
-            except Exception:
-                traffic = None
-        info = r.info()
-        line = {
-            "metric": "Mrays/sec (whole node) @4K ~500 spheres",
-            "value": total_rays / elapsed / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"rtiow-layout scene seed {SCENE_SEED} ({scene.sphere_count} spheres), {WIDTH}x{HEIGHT}, "
-                            f"{fps} frames (spp) per step per GPU, max depth {args.max_depth}, "
-                            f"float profile {args.profile}, kernel {args.kernel}"
-                            + (", material extension on" if args.materials else ""),
-                "parallelism": f"samples split by frame number over {world} GPU(s), one RCCL sum-reduce at the end",
-                "launch": f"{info['blocks']} x {info['threads']}",
-            },
-            "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
-            "roofline": {
-                "bound": "valu",
-                "bound_detail": "FP32 vector ALU: the path has no matrix contraction, so neither HBM nor MFMA bounds it; "
-                                "the FP32 vector peak equals the dense FP32 MFMA peak (157.3 TFLOP/s)",
-                "achieved": achieved,
-                "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_TFLOPS,
-                "traffic": traffic,
-                "kernel_ms_per_launch": launch_ms,
-                "flop_per_test": FLOP_PER_TEST,
-                "hbm_algorithmic_GBps": WIDTH // 8 * 8 * (HEIGHT // 8 * 8) * BYTES_PER_PIXEL_DISPATCH
-                                        / (launch_ms * 1e-3) / 1e9,
-            },
-        }
-        if args.cpu_seconds > 0 and world == 1:  # the CPU leg runs at N=1 only
-            line["cpu_baseline"] = cpu_baseline(scene, profile, args.max_depth, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-
-    r.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -179,6 +179,13 @@ int rt_reset_counters(rt_context* ctx);
 int rt_timer_begin(rt_context* ctx);
 int rt_timer_end(rt_context* ctx, float* ms);
 
+/* rt_dispatch_frames bracketed by a HIP event pair of its own, so that the device time of every
+   dispatch can be had without a host synchronisation between them; rt_timed_total synchronises
+   the stream and returns the summed device time (ms) and the number of timed dispatches since
+   it was last called.  No reference counterpart. */
+int rt_dispatch_frames_timed(rt_context* ctx, int n_frames);
+int rt_timed_total(rt_context* ctx, float* ms, int* dispatches);
+
 /* Launch geometry of the stream kernel (0 = choose from the device).  No reference
    counterpart: the shader's is fixed at local_size 8x8 (res/shaders/shader.comp:2). */
 int rt_set_launch(rt_context* ctx, int blocks, int threads_per_block);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "rt_reset_counters": (C.c_int, [_P]),
     "rt_timer_begin": (C.c_int, [_P]),
     "rt_timer_end": (C.c_int, [_P, _F]),
+    "rt_dispatch_frames_timed": (C.c_int, [_P, C.c_int]),
+    "rt_timed_total": (C.c_int, [_P, _F, C.POINTER(C.c_int)]),
     "rt_set_launch": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_get_info": (C.c_int, [_P] + [C.POINTER(C.c_int)] * 4),
     "rt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int]),

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_internal.h"
@@ -101,6 +102,8 @@ struct rt_context {
     int clear_mode = RT_CLEAR_REFERENCE;
     int blocks = 0, threads = 0;  // 0 = automatic
     bool fail_next_launch = false;  // rt_debug_fail_next_launch
+    // rt_dispatch_frames_timed: event pairs around dispatches not yet read by rt_timed_total
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_pending, timed_free;
 };
 
 namespace {
@@ -584,6 +587,11 @@ int rt_destroy(rt_context* c)
     if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);
+    for (auto* list : {&c->timed_pending, &c->timed_free})
+        for (auto& ev : *list) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -782,6 +790,60 @@ int rt_dispatch_frames(rt_context* c, int n_frames)
 }
 
 int rt_dispatch(rt_context* c) { return rt_dispatch_frames(c, 1); }
+
+int rt_dispatch_frames_timed(rt_context* c, int n_frames)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    RT_ON_DEVICE(c);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (!c->timed_free.empty()) {
+        ev = c->timed_free.back();
+        c->timed_free.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&ev.first));
+        const hipError_t e = hipEventCreate(&ev.second);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(ev.first);
+            return fail(RT_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    hipError_t e = hipEventRecord(ev.first, c->stream);
+    int rc = e == hipSuccess ? rt_dispatch_frames(c, n_frames) : fail(RT_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+    if (rc == RT_OK) {
+        e = hipEventRecord(ev.second, c->stream);
+        if (e != hipSuccess) rc = fail(RT_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+    }
+    try {
+        (rc == RT_OK ? c->timed_pending : c->timed_free).push_back(ev);
+    } catch (const std::bad_alloc&) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+        return rc == RT_OK ? fail(RT_E_NOMEM, "out of host memory") : rc;
+    }
+    return rc;
+}
+
+int rt_timed_total(rt_context* c, float* ms, int* dispatches)
+{
+    if (!c || !ms) return fail(RT_E_INVALID, "null argument");
+    RT_ON_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double total = 0.0;
+    int n = 0;
+    while (!c->timed_pending.empty()) {
+        const auto ev = c->timed_pending.back();
+        c->timed_pending.pop_back();
+        float t = 0.f;
+        const hipError_t e = hipEventElapsedTime(&t, ev.first, ev.second);
+        c->timed_free.push_back(ev);  // capacity was reserved when it was pending: pending + free never grows here
+        if (e != hipSuccess) return fail(RT_E_HIP, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        total += t;
+        n++;
+    }
+    *ms = (float)total;
+    if (dispatches) *dispatches = n;
+    return RT_OK;
+}
 
 int rt_sync(rt_context* c)
 {

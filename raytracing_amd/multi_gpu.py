@@ -40,13 +40,17 @@ class SampleSplit:
         clear = CLEAR_FIRST if (step == 0 or restart) else CLEAR_NEVER
         return first, self.world, frames_per_step, clear
 
-    def dispatch(self, renderer, scene, step: int, frames_per_step: int, restart: bool = False) -> None:
+    def dispatch(self, renderer, scene, step: int, frames_per_step: int, restart: bool = False,
+                 timed: bool = False) -> None:
         first, stride, n, clear = self.schedule(step, frames_per_step, restart)
         renderer.set_frame_schedule(stride, clear)
         ubo = scene.camera.copy()
         ubo["frameCount"][0] = first
         renderer.set_uniforms(ubo)
-        renderer.dispatch(n)
+        if timed:
+            renderer.dispatch_timed(n)  # with an event pair of its own (Renderer.timed_total)
+        else:
+            renderer.dispatch(n)
 
     def reduce(self, accum, dst: int = 0) -> None:
         """Sum the per-rank accumulation images into rank `dst` (RCCL on GPUs, gloo on CPU)."""
@@ -104,3 +108,44 @@ class TileSplit:
             r0, r1 = self.rows
             if r1 > r0:
                 dist.send(image[r0 * 8:r1 * 8].contiguous(), dst=dst)
+
+
+class InteractiveLoop:
+    """The interactive tile split, pipelined one frame deep: frame f is traced into one of two
+    colour images while the bands of frame f-1 travel to the display rank out of the other, so
+    the exchange of a frame overlaps the tracing of the next one.
+
+    `renderer` needs set_uniforms / dispatch / sync; `bind_color(k)` makes colour image k (0 or 1)
+    the one the next dispatch writes and returns only when the previous dispatch has finished
+    (Renderer.bind_buffers does both); `images[k]` is the H x W [x C] tensor of image k that is
+    exchanged (a host copy when the backend cannot move device memory).  `on_frame(f, image)` is
+    called on the display rank with every completed frame, in order.
+    """
+
+    def __init__(self, tiles: TileSplit, renderer, bind_color, image_of, on_frame=None, dst: int = 0,
+                 dispatch=None):
+        self.tiles, self.renderer, self.bind_color, self.image_of = tiles, renderer, bind_color, image_of
+        self.on_frame, self.dst = on_frame, dst
+        self.dispatch = dispatch or (lambda: renderer.dispatch(1))
+        self.count = 0
+
+    def _deliver(self, f: int) -> None:
+        image = self.image_of(f % 2)
+        self.tiles.gather(image, dst=self.dst)
+        if self.on_frame is not None and self.tiles.rank == self.dst:
+            self.on_frame(f, image)
+
+    def frame(self, ubo) -> None:
+        f = self.count
+        self.bind_color(f % 2)          # returns once frame f-1 is complete in the other image
+        self.renderer.set_uniforms(ubo)
+        self.dispatch()                 # asynchronous on a GPU
+        if f > 0:
+            self._deliver(f - 1)        # ... so frame f-1 is exchanged while frame f is traced
+        self.count = f + 1
+
+    def finish(self) -> None:
+        if self.count > 0:
+            self.renderer.sync()
+            self._deliver(self.count - 1)
+            self.count = 0

@@ -113,6 +113,16 @@ class Renderer:
     def dispatch(self, n_frames: int = 1) -> None:
         N.check(N.lib().rt_dispatch_frames(self._h, n_frames))
 
+    def dispatch_timed(self, n_frames: int = 1) -> None:
+        """dispatch() bracketed by an event pair of its own; timed_total() sums them."""
+        N.check(N.lib().rt_dispatch_frames_timed(self._h, n_frames))
+
+    def timed_total(self):
+        """(device milliseconds, dispatches) of the dispatch_timed calls since the last call; synchronises."""
+        ms, n = C.c_float(), C.c_int()
+        N.check(N.lib().rt_timed_total(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def sync(self) -> None:
         N.check(N.lib().rt_sync(self._h))
 

@@ -22,29 +22,71 @@ def _one_json_line(stdout):
     return json.loads(lines[0])
 
 
-def test_bench_single_rank_line():
-    res = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--frames-per-step", "2",
-                          "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+def _check_roofline(line, culled=False):
+    roof = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm"} <= set(roof)
+    if not culled:
+        assert 0.0 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    hbm = roof["hbm"]
+    assert hbm["unit"] == "GB/s" and 0.0 < hbm["frac"] < 1.0 and abs(hbm["frac"] - hbm["achieved"] / hbm["peak"]) < 1e-9
+    assert roof["launches"] == line["steps"] and roof["kernel_ms_per_launch"] > 0
+    # device time of the kernel launches cannot exceed the wall time of the steps
+    assert roof["kernel_ms_per_launch"] <= line["ms_per_step"] * 1.001
+    assert (roof["traffic"] is None) == (roof["traffic_source"] is None)
+
+
+@pytest.mark.parametrize("workload,unit", [("rtiow4k", "Mrays/s"), ("default720p_d8", "Mrays/s"),
+                                           ("default1080p", "Mrays/s"), ("stress4096", "Mrays/s"),
+                                           ("interactive", "ms")])
+def test_bench_single_rank_line(workload, unit):
+    steps = "20" if workload == "interactive" else "2"
+    cmd = [sys.executable, "bench.py", "--workload", workload, "--steps", steps, "--warmup", "1", "--cpu-seconds", "1"]
+    if workload != "interactive":
+        cmd += ["--frames-per-step", "2"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     line = _one_json_line(res.stdout)
     assert KEYS <= set(line) and "cpu_baseline" in line
-    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
-    assert line["unit"] == "Mrays/s" and line["value"] > 1000.0 and line["higher_is_better"] is True
-    roof = line["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
-    assert 0.0 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert line["n_gpus"] == 1 and line["steps"] == int(steps) and line["warmup"] == 1
+    assert line["unit"] == unit and line["value"] > 0
+    if unit == "Mrays/s":
+        assert line["higher_is_better"] is True and line["scaling"] == "weak"
+        assert line["value"] > (1000.0 if workload != "stress4096" else 100.0)
+    else:
+        assert line["higher_is_better"] is False and line["value"] < 50.0
+    _check_roofline(line)
     cpu = line["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["value"] > 0
-    assert "workload" in line["config"] and "model" not in line["config"]
+    assert cpu["unit"] == ("ms/frame" if unit == "ms" else "Mrays/s")
+    assert workload in line["config"]["workload"] and "model" not in line["config"]
 
 
+def test_bench_culled_kernel_does_not_claim_brute_force_flops():
+    res = subprocess.run([sys.executable, "bench.py", "--kernel", "culled", "--steps", "2", "--warmup", "1",
+                          "--frames-per-step", "2", "--cpu-seconds", "0"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = _one_json_line(res.stdout)
+    assert line["roofline"]["frac"] is None and "brute-force-equivalent" in line["roofline"]["note"]
+    _check_roofline(line, culled=True)
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
 @pytest.mark.parametrize("workload", ["rtiow4k", "interactive"])
-def test_bench_two_ranks_rehearsal(workload):
+def test_bench_two_ranks_rehearsal(workload, launcher):
+    """Two ranks on one GPU with gloo standing in for RCCL, started the way the driver starts them
+    (torch.distributed.run) and by plain `python bench.py --gpus 2`, which spawns its ranks itself."""
     env = dict(os.environ, RT_BENCH_DEVICE="0", RT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
     port = "29617" if workload == "rtiow4k" else "29618"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--frames-per-step", "2", "--cpu-seconds", "0", "--workload", workload]
+    tail = ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--workload", workload]
+    if workload != "interactive":
+        tail += ["--frames-per-step", "2"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", port] + tail
+    else:
+        cmd = [sys.executable] + tail
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = _one_json_line(res.stdout)
@@ -53,4 +95,11 @@ def test_bench_two_ranks_rehearsal(workload):
     if workload == "rtiow4k":
         assert line["scaling"] == "weak" and line["unit"] == "Mrays/s"
     else:
-        assert line["unit"] == "ms" and line["higher_is_better"] is False
+        assert line["unit"] == "ms" and line["higher_is_better"] is False and line["scaling"] == "strong"
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "must agree" in res.stderr

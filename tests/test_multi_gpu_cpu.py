@@ -19,7 +19,7 @@ import torch.multiprocessing as mp
 
 import oracle as O
 import raytracing_amd as rt
-from raytracing_amd.multi_gpu import SampleSplit, TileSplit
+from raytracing_amd.multi_gpu import InteractiveLoop, SampleSplit, TileSplit
 
 W, H = 96, 72  # 9 tile rows: an odd number, so the two bands differ in size
 
@@ -32,6 +32,9 @@ class OracleRenderer:
         self.accum = np.zeros((height, width, 4), np.float32)
         self.color = np.zeros((height, width, 4), np.uint8)
         self.stride, self.clear, self.rows, self.ubo = 1, 0, None, None
+
+    def sync(self):
+        pass
 
     def set_frame_schedule(self, stride, clear):
         self.stride, self.clear = stride, clear
@@ -88,8 +91,41 @@ def _worker(rank, world, port, out_dir):
         if rank == 0:
             np.save(os.path.join(out_dir, "tile_color.npy"), col.numpy())
             np.save(os.path.join(out_dir, "bands.npy"), np.array(tiles.bands))
+        # --- interactive loop: 7 frames with a moving camera and resets, two colour images,
+        #     frame f exchanged after frame f+1 has been dispatched
+        r3 = OracleRenderer(scene, W, H)
+        tiles.apply(r3)
+        images = [torch.zeros((H, W, 4), dtype=torch.uint8) for _ in range(2)]
+        shown = []
+
+        def bind_color(k):
+            r3.color = images[k].numpy()  # the stand-in writes straight into image k
+
+        loop = InteractiveLoop(tiles, r3, bind_color, lambda k: images[k],
+                               on_frame=lambda f, img: shown.append(img.numpy().copy()))
+        for ubo in _interactive_ubos(7):
+            loop.frame(ubo)
+        loop.finish()
+        if rank == 0:
+            np.save(os.path.join(out_dir, "interactive.npy"), np.stack(shown))
     finally:
         dist.destroy_process_group()
+
+
+def _interactive_ubos(n):
+    """Uniform blocks of n frames in which the camera moves on some frames (frameCount restarts at
+    1, as Scene::update does when the camera has moved) and rests on the others."""
+    scene = rt.Scene.default()
+    out, count = [], 0
+    for i in range(n):
+        moved = i in (0, 3, 5, 6)
+        if moved:
+            scene.camera["camera_position"][0][2] += 0.25
+        count = 1 if moved else count + 1
+        ubo = scene.camera.copy()
+        ubo["frameCount"][0] = count
+        out.append(ubo)
+    return out
 
 
 def test_schedules():
@@ -131,3 +167,11 @@ def test_world_size_two_gloo(tmp_path, default_scene):
     _, col, _ = O.render(ubo, default_scene.spheres, W, H, n_frames=1)
     assert np.array_equal(np.load(tmp_path / "tile_color.npy"), col)
     assert np.load(tmp_path / "bands.npy").tolist() == [[0, 5], [5, 9]]
+    # interactive loop: every displayed frame equals the single-process frame, bit for bit, in order
+    shown = np.load(tmp_path / "interactive.npy")
+    ubos = _interactive_ubos(7)
+    assert shown.shape[0] == 7 and len({int(u["frameCount"][0]) for u in ubos}) > 1
+    acc = None
+    for f, u in enumerate(ubos):
+        acc, col, _ = O.render(u, default_scene.spheres, W, H, n_frames=1, accum=acc)
+        assert np.array_equal(shown[f], col), f

@@ -1,22 +1,32 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): kernel statistics and HBM traffic counters of `python3 bench.py`.
-# Four separate rocprofv3 runs (timing; FETCH_SIZE; WRITE_SIZE; SQ instruction counts), each under its own time limit.
-# Results land in gpurun_out/prof/<tag>/; tools/summarise_profiles.py turns them into profiles/.
-#   usage: tools/collect_profiles.sh TAG [bench.py arguments]
+# Run on the GPU box (through gpurun): kernel statistics and hardware counters of one bench.py workload.
+# Separate rocprofv3 runs (timing; FETCH_SIZE; WRITE_SIZE; SQ + GRBM counters), each under its own time limit.
+# Results land in gpurun_out/prof/<tag>/<workload>/; tools/summarise_profiles.py turns them into profiles/.
+#   usage: tools/collect_profiles.sh TAG WORKLOAD [more bench.py arguments]
 set -e
-tag=$1; shift
+tag=$1; wl=$2; shift 2
 root=$(pwd)
-out=$root/gpurun_out/prof/$tag
+out=$root/gpurun_out/prof/$tag/$wl
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
+args="--workload $wl --cpu-seconds 0 $*"
+echo "$args" > "$out/bench_args.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
-    python3 bench.py --cpu-seconds 0 "$@" > "$out/bench_stats.log" 2>&1
+    python3 bench.py $args > "$out/bench_stats.log" 2>&1
 grep '^{' "$out/bench_stats.log" > "$out/bench_line.json"
-timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o bench -- \
-    python3 bench.py --cpu-seconds 0 "$@" > "$out/bench_fetch.log" 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o bench -- \
-    python3 bench.py --cpu-seconds 0 "$@" > "$out/bench_write.log" 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES \
+timeout -s KILL 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o bench -- \
+    python3 bench.py $args > "$out/bench_fetch.log" 2>&1
+timeout -s KILL 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o bench -- \
+    python3 bench.py $args > "$out/bench_write.log" 2>&1
+timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES \
+    SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \
     --output-format csv -d "$out/pmc_sq" -o bench -- \
-    python3 bench.py --cpu-seconds 0 "$@" > "$out/bench_sq.log" 2>&1
-find "$out" -name "*.csv" | sort
+    python3 bench.py $args > "$out/bench_sq.log" 2>&1
+timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA \
+    SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 \
+    --output-format csv -d "$out/pmc_wait" -o bench -- \
+    python3 bench.py $args > "$out/bench_wait.log" 2>&1 || echo "wait pass failed (optional)"
+# the unprofiled line of the same command, for the record next to the profiled one
+timeout -k 10 300 python3 bench.py $args > "$out/bench_plain.log" 2>&1
+grep '^{' "$out/bench_plain.log" > "$out/bench_line_plain.json"
+echo "collected $wl"

@@ -1,62 +1,118 @@
 #!/usr/bin/env python3
 """Turn the output of tools/collect_profiles.sh into the committed summaries under profiles/.
 
-usage: python tools/summarise_profiles.py TAG [steps=8]
+usage: python tools/summarise_profiles.py TAG WORKLOAD [WORKLOAD ...]
 
-Writes profiles/<TAG>_bench_kernel_stats.csv, profiles/<TAG>_bench_line.json and updates
-profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernel, which bench.py reports
-as roofline.traffic).  FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half
-the bytes of wide coalesced reads, so it is doubled (see the comment in the JSON).
+Per workload: profiles/<TAG>_<workload>_kernel_stats.csv (rocprofv3 --kernel-trace --stats),
+profiles/<TAG>_<workload>_bench_line.json (the JSON line of that profiled run and of an
+unprofiled run of the same command) and profiles/<TAG>_<workload>_counters.json (per-launch means
+of every counter collected).  All workloads: profiles/<TAG>_pmc.json, keyed
+<workload>_<kernel>_<profile>, which bench.py reads for roofline.traffic, valu_busy, clock_ghz and
+executed_flop_frac.
+
+Units and corrections: FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts half the
+bytes of wide coalesced reads, so it is doubled.  GRBM_GUI_ACTIVE is summed over the 8 XCDs:
+clock = GRBM_GUI_ACTIVE / 8 / kernel time.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over
+the SIMDs: VALU busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8).
 """
+import collections
 import csv
+import glob
 import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SIMD = 1024
+PEAK_TFLOPS = 157.3
+EXECUTED_FLOP_PER_TEST = 15.0  # the sieve as compiled: 7 v_pk_fma_f32 + 1 v_pk_add_f32 per sphere PAIR = 30 flop / 2
+KERNELS = ("rt_stream_kernel", "rt_tile_kernel", "rt_mfma_kernel", "rt_small_kernel")
 
 
-def counter_per_launch(path, kernel, counter, steps):
-    rows = [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    vals = [float(r["Counter_Value"]) for r in rows][-steps:]  # the timed launches are the last ones
-    return sum(vals) / len(vals), vals
+def per_launch(path, timed):
+    """{counter: mean over the last `timed` launches}, mean duration (ns) of those launches, kernel name."""
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in KERNELS)]
+    by = collections.defaultdict(list)
+    for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+        by[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out, dur = {}, None
+    for name, v in by.items():
+        v = v[-timed:]
+        out[name] = sum(x for x, _ in v) / len(v)
+        dur = sum(d for _, d in v) / len(v)
+    return out, dur, (rows[0]["Kernel_Name"].split("(")[0] if rows else None)
+
+
+def one(tag, wl, pmc_all):
+    src = os.path.join(ROOT, "gpurun_out", "prof", tag, wl)
+    dst = os.path.join(ROOT, "profiles")
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
+    line = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
+    plain = None
+    try:
+        plain = json.loads(open(os.path.join(src, "bench_line_plain.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    json.dump({"command": "python3 bench.py " + open(os.path.join(src, "bench_args.txt")).read().strip(),
+               "under_rocprofv3_kernel_trace": line, "unprofiled": plain},
+              open(os.path.join(dst, f"{tag}_{wl}_bench_line.json"), "w"), indent=1)
+    timed = int(line["roofline"]["launches"])
+    counters, durations, kernel = {}, {}, None
+    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait"):
+        files = glob.glob(os.path.join(src, p, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        c, dur, k = per_launch(files[0], timed)
+        kernel = kernel or k
+        counters.update(c)
+        for name in c:
+            durations[name] = dur
+    rec = {"_comment": f"per-launch means over the {timed} timed launches of `{kernel}` in `python3 bench.py "
+                       + open(os.path.join(src, "bench_args.txt")).read().strip() + "`, one rocprofv3 --pmc pass per "
+                       "counter group (tools/collect_profiles.sh); *_ns = mean launch duration in the pass that counter came from",
+           "counters": counters, "duration_ns": durations}
+    json.dump(rec, open(os.path.join(dst, f"{tag}_{wl}_counters.json"), "w"), indent=1)
+
+    key = f"{wl}_stream_strict"
+    out = {}
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        out["fetch_bytes_per_launch"] = counters["FETCH_SIZE"] * 1024 * 2
+        out["write_bytes_per_launch"] = counters["WRITE_SIZE"] * 1024
+        out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+    if "GRBM_GUI_ACTIVE" in counters:
+        cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
+        out["clock_ghz"] = cyc / durations["GRBM_GUI_ACTIVE"]
+        if "SQ_ACTIVE_INST_VALU" in counters:
+            out["valu_busy"] = 4.0 * counters["SQ_ACTIVE_INST_VALU"] / N_SIMD / cyc
+        if "SQ_INSTS_VALU" in counters:
+            out["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"]
+    tests_per_launch = line["roofline"]["achieved"] * 1e12 * line["roofline"]["kernel_ms_per_launch"] * 1e-3 / line["roofline"]["flop_per_test"]
+    out["executed_flop_frac"] = (tests_per_launch * EXECUTED_FLOP_PER_TEST / (line["roofline"]["kernel_ms_per_launch"] * 1e-3)
+                                 / 1e12 / PEAK_TFLOPS)
+    out["executed_flop_note"] = "sieve only: 15 FP32 flop executed per ray-sphere test (7 v_pk_fma_f32 + 1 v_pk_add_f32 per sphere pair)"
+    out["kernel_ms_per_launch_rocprof_stats"] = None
+    for r in csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))):
+        if any(k in r["Name"] for k in KERNELS):
+            out["kernel_ms_per_launch_rocprof_stats"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_calls"] = int(r["Calls"])
+            break
+    out["kernel_ms_per_launch_bench"] = line["roofline"]["kernel_ms_per_launch"]
+    pmc_all[key] = out
+    print(wl, json.dumps(out, indent=1))
 
 
 def main():
     tag = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    src = os.path.join(ROOT, "gpurun_out", "prof", tag)
-    dst = os.path.join(ROOT, "profiles")
-    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-    line = json.load(open(os.path.join(src, "bench_line.json")))
-    json.dump(line, open(os.path.join(dst, f"{tag}_bench_line.json"), "w"), indent=1)
-    kernel = "rt_stream_kernel"
-    fetch_kib, fv = counter_per_launch(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"), kernel, "FETCH_SIZE", steps)
-    write_kib, wv = counter_per_launch(os.path.join(src, "pmc_write", "bench_counter_collection.csv"), kernel, "WRITE_SIZE", steps)
-    fetch = fetch_kib * 1024 * 2
-    write = write_kib * 1024
-    px = 3840 * 2160
-    out = {
-        "_comment": "HBM bytes per launch of rt_stream_kernel in `python bench.py` (8 frames per step, 3840x2160): "
-                    "mean over the timed launches of FETCH_SIZE (KiB, doubled: gfx950 reports half the bytes of a "
-                    "wide coalesced read) + WRITE_SIZE (KiB), collected in separate rocprofv3 --pmc passes "
-                    f"(tools/collect_profiles.sh, tag {tag}). Algorithmic: 16 B read (except in the clearing first "
-                    "step of a pass) + 16 B accumulation + 4 B rgba8 written per pixel "
-                    f"= {px * 36 / 1e6:.0f} MB ({px * 20 / 1e6:.0f} MB for the clearing step).",
-        "stream_strict_fps8": fetch + write,
-        "fetch_bytes": fetch,
-        "write_bytes": write,
-        "per_launch_fetch_KiB": fv,
-        "per_launch_write_KiB": wv,
-    }
-    json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(out, indent=1))
-    for r in csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))):
-        if kernel in r["Name"]:
-            print("kernel stats:", r["Calls"], "calls, average", float(r["AverageNs"]) / 1e6, "ms; bench.py measured",
-                  line["roofline"]["kernel_ms_per_launch"], "ms")
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+    pmc_all = json.load(open(path)) if os.path.exists(path) else {}
+    pmc_all["_comment"] = ("per workload (key <workload>_<kernel>_<profile>): HBM bytes per launch from FETCH_SIZE (doubled: gfx950 "
+                           "reports half the bytes of wide coalesced reads) + WRITE_SIZE; clock = GRBM_GUI_ACTIVE / 8 XCDs / launch "
+                           "time; valu_busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); "
+                           "tools/collect_profiles.sh + tools/summarise_profiles.py")
+    for wl in sys.argv[2:]:
+        one(tag, wl, pmc_all)
+    json.dump(pmc_all, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":
