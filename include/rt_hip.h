@@ -52,6 +52,9 @@ enum {
     RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
     RT_KERNEL_STREAM_SGPR = 2, /* STREAM, sieve geometry read through the scalar cache (SGPRs) */
     RT_KERNEL_STREAM_LDS = 3,  /* STREAM, sieve geometry read from the LDS copy                */
+    RT_KERNEL_STREAM_MFMA = 5, /* STREAM with the sieve's two dot products (rays x spheres, K = 4) evaluated by the
+                                  matrix cores on exact three-term bf16 splits of the f32 operands; the vector
+                                  ALU keeps 2 instructions per test.  Up to 1024 traced spheres, else STREAM. */
     RT_KERNEL_STREAM_CULLED = 4 /* STREAM over a spatially sorted copy of the sphere list: groups of 8
                                   spheres whose bounding sphere no ray of the wave can touch are
                                   skipped.  Not brute force any more (the step the reference's

@@ -72,6 +72,8 @@ struct rt_context {
     RtSphereAos* d_spheres = nullptr;  // AoS copy
     float4* d_geom = nullptr;  // pair-packed sieve geometry
     float* d_radius = nullptr; // radii, padded
+    uint4* d_frags = nullptr;  // sphere-side operands of the matrix-core sieve, room for RT_MAX_MFMA_SPHERES
+    bool have_frags = false;   // d_frags describes the uploaded spheres (false: too many of them)
     float2* d_materials = nullptr;  // material extension: {kind, param} per sphere
     int material_cap = 0;
     bool have_materials = false;    // true when some sphere has a kind other than 0
@@ -232,14 +234,62 @@ int make_params(rt_context* c, int n_frames, RtParams* out)
 
 // w of the sieve geometry: r*r - c.c + margin*(c.c + r*r), evaluated in double and rounded UP to
 // float so the margin is never eroded (see sieve_pair in rt_kernels.hip).
-float sieve_w(double cx, double cy, double cz, double r)
+float sieve_w(double cx, double cy, double cz, double r, double margin = RT_SIEVE_MARGIN)
 {
     const double cc = cx * cx + cy * cy + cz * cz;
     const double rr = r * r;
-    const double w = rr - cc + (double)RT_SIEVE_MARGIN * (cc + rr);
+    const double w = rr - cc + margin * (cc + rr);
     float wf = (float)w;
     if ((double)wf < w) wf = std::nextafter(wf, INFINITY);
     return wf;
+}
+
+// Sphere-side operands of the sieve on the matrix cores ("sieve on the matrix cores" in
+// rt_kernels.hip has the layout): per chunk of 32 spheres and MFMA step s, lane l = (row r = l & 31,
+// half h = l >> 5) holds eight bf16: the three-term split a1 + a2 + a3 of coordinate d = 2 s + h of
+// the sphere in row r, ordered a_p[j], p = 1 1 2 2 1 3 2 3; coordinate 3 is {w1, w2, w3, 1, 1, 1, 0, 0}.
+// Row r holds sphere 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3) of the chunk.  A sphere with a
+// non-finite centre, radius or w can never be hit by the shader's test (its t is never a finite
+// positive number), so it gets operands that are always rejected, like the padding.
+void build_mfma_frags(const std::vector<RtSphereAos>& padded, std::vector<uint32_t>* out)
+{
+    const int cap = (int)padded.size();
+    out->assign((size_t)cap * 16, 0u);
+    auto bits = [](float x) { uint32_t u; memcpy(&u, &x, 4); return u; };
+    auto flt = [](uint32_t u) { float x; memcpy(&x, &u, 4); return x; };
+    auto split3 = [&](float x, uint32_t t[3]) {  // high halves of the three terms
+        t[0] = bits(x) & 0xffff0000u;
+        const float r1 = x - flt(t[0]);
+        t[1] = bits(r1) & 0xffff0000u;
+        const float r2 = r1 - flt(t[1]);
+        t[2] = bits(r2) & 0xffff0000u;
+        for (int k = 0; k < 3; k++) t[k] >>= 16;
+    };
+    const uint32_t one = 0x3f80u;
+    for (int ch = 0; ch < cap / RT_CHUNK; ch++)
+        for (int step = 0; step < 2; step++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int r = lane & 31, h = lane >> 5, d = 2 * step + h;
+                const RtSphereAos& sp = padded[(size_t)ch * RT_CHUNK + 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3)];
+                float w = sieve_w(sp.cx, sp.cy, sp.cz, sp.radius, RT_SIEVE_MARGIN_MFMA);
+                float c[3] = {sp.cx, sp.cy, sp.cz};
+                if (!std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2]) || !std::isfinite(w)) {
+                    c[0] = c[1] = c[2] = 0.f;
+                    w = -3.0e38f;
+                }
+                uint32_t e[8];
+                uint32_t t[3];
+                if (d < 3) {
+                    split3(c[d], t);
+                    const int p_of[8] = {0, 0, 1, 1, 0, 2, 1, 2};
+                    for (int j = 0; j < 8; j++) e[j] = t[p_of[j]];
+                } else {
+                    split3(w, t);
+                    e[0] = t[0]; e[1] = t[1]; e[2] = t[2]; e[3] = e[4] = e[5] = one; e[6] = e[7] = 0u;
+                }
+                uint32_t* dst = out->data() + (((size_t)ch * 2 + step) * 64 + lane) * 4;
+                for (int k = 0; k < 4; k++) dst[k] = e[2 * k] | (e[2 * k + 1] << 16);
+            }
 }
 
 uint32_t morton10(uint32_t v)  // spread the low 10 bits of v three apart
@@ -386,6 +436,13 @@ void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* t
     rt_stream_geometry(c->cu_count, c->blocks, c->threads, P, blocks, threads);
 }
 
+// Whether this dispatch runs the sieve on the matrix cores (mode 3 of rt_launch_stream).
+bool wants_mfma(const rt_context* c, const RtParams& P)
+{
+    const bool can = c->have_frags && P.n_pad > 0 && P.n_pad <= RT_MAX_MFMA_SPHERES;
+    return can && c->kernel == RT_KERNEL_STREAM_MFMA;
+}
+
 }  // namespace
 
 // Workgroup size and count of the persistent kernel.  The kernel is bound by VALU issue, which
@@ -397,9 +454,10 @@ void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* t
 void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const RtParams& P, int* blocks,
                         int* threads)
 {
-    int t = want_threads > 0 ? want_threads : (P.n_lds <= 1024 ? 256 : 1024);
+    const bool mfma = P.frags != nullptr;  // the operand fragments are staged in LDS too: larger workgroups share them
+    int t = want_threads > 0 ? want_threads : (mfma ? 512 : P.n_lds <= 1024 ? 256 : 1024);
     t = std::max(64, std::min(1024, t / 64 * 64));
-    const size_t lds = rt_stream_lds_bytes(P.n_lds, t);
+    const size_t lds = rt_stream_lds_bytes(P.n_lds, t, mfma);
     const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
     int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)cu_count ? 8 : 12;
     if (t == 1024) waves_per_cu = 16;  // whole workgroups: one per CU
@@ -485,9 +543,11 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         HIP_TRY(rt_launch_tile(P, fused, record, c->stream));
         return RT_OK;
     }
+    const bool mfma = wants_mfma(c, P);
+    P.frags = mfma ? c->d_frags : nullptr;
     int blocks, threads;
     stream_geometry(c, P, &blocks, &threads);
-    if (rt_stream_lds_bytes(P.n_lds, threads) > kLdsPerCu)
+    if (rt_stream_lds_bytes(P.n_lds, threads, mfma) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
@@ -499,6 +559,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     int mode = c->kernel == RT_KERNEL_STREAM_SGPR || c->kernel == RT_KERNEL_STREAM_CULLED ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES)
                    ? 1 : 0;
+    if (mfma) mode = 3;
     if (c->kernel == RT_KERNEL_STREAM_CULLED) {
         bool on = false;
         const int rc = use_culled(c, &P, &on);
@@ -580,6 +641,7 @@ int rt_destroy(rt_context* c)
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_radius) (void)hipFree(c->d_radius);
+    if (c->d_frags) (void)hipFree(c->d_frags);
     if (c->d_materials) (void)hipFree(c->d_materials);
     if (c->d_cgeom) (void)hipFree(c->d_cgeom);
     if (c->d_cradius) (void)hipFree(c->d_cradius);
@@ -658,6 +720,18 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     HIP_TRY(hipMemcpy(c->d_spheres, host.data(), (size_t)cap * sizeof(RtSphereAos), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_geom, geom.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_radius, radius.data(), (size_t)cap * sizeof(float), hipMemcpyHostToDevice));
+    c->have_frags = false;
+    if (cap <= RT_MAX_MFMA_SPHERES) {
+        if (!c->d_frags) HIP_TRY(hipMalloc(&c->d_frags, (size_t)RT_MAX_MFMA_SPHERES * 4 * sizeof(uint4)));
+        std::vector<uint32_t> frags;
+        try {
+            build_mfma_frags(host, &frags);
+        } catch (const std::bad_alloc&) {
+            return fail(RT_E_NOMEM, "out of host memory staging %d spheres", count);
+        }
+        HIP_TRY(hipMemcpy(c->d_frags, frags.data(), frags.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->have_frags = true;
+    }
     c->n_spheres = count;
     c->have_materials = false;  // materials belong to a sphere list: upload them again
     c->cull_count = -1;         // so does the sorted copy of the culled kernel
@@ -726,7 +800,7 @@ int rt_set_profile(rt_context* c, int profile)
 int rt_set_kernel(rt_context* c, int kernel)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_STREAM_CULLED)
+    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_STREAM_MFMA)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
@@ -1087,6 +1161,7 @@ int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t 
     int rc = make_params(c, 1, &P);
     if (rc != RT_OK) return rc;
     if (P.n_lds == 0 && P.n_pad) return fail(RT_E_INVALID, "too many spheres for the sieve audit");
+    P.frags = wants_mfma(c, P) ? c->d_frags : nullptr;  // audits the sieve the context's kernel would run
     float* d_rays = nullptr;
     unsigned long long* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 6 * sizeof(float)));

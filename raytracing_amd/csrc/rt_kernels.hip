@@ -33,6 +33,10 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 #define RT_FLT_MAX 3.402823466e+38f  // def.glsl:27
 
@@ -556,6 +560,134 @@ __device__ __forceinline__ uint32_t sieve_chunk_culled(GeomPtr g, const SieveRay
     return mask;
 }
 
+// ------------------------------------------------- sieve on the matrix cores
+//
+// The same conservative test g = s^2 + t (sieve_pair above) with its two dot products
+//     s = c . (-n) + d0,        t = c . (2 o) + w - o.o (1 - margin)
+// evaluated for 32 spheres x 32 rays at a time by v_mfma_f32_32x32x16_bf16: a dense contraction
+// over K = 4 coordinates.  Every f32 operand x is split exactly into three bf16 terms
+// x = x1 + x2 + x3 (truncation: each term holds the next 8 significant bits), and a product
+// a b is the sum of the eight partial products a_p b_q other than a3 b3 (which is below
+// 2^-32 |a b|); each partial product of two bf16 is exact in f32, the matrix core accumulates in
+// f32.  So one dot product is a K = 4 x 8 = 32 contraction = two MFMA steps per 32 x 32 tile:
+//   step s, lane half h  <->  coordinate d = 2 s + h   (0: x, 1: y, 2: z, 3: the constants)
+//   element j of a fragment <-> partial product (p, q)[j] = (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) (2,3) (3,2)
+// Sphere side (A operand, from LDS, built by the host: rt_api.cpp build_mfma_frags): elements
+// a_p[j] of coordinate d; for d = 3  {w1, w2, w3, 1, 1, 1, 0, 0}.  Ray side (B operand): b_q[j];
+// for d = 3 the s-product carries {0, 0, 0, e1, e2, e3, 0, 0}, e = d0, and the t-product
+// {1, 1, 1, k1, k2, k3, 0, 0}, k = -o.o (1 - margin): the constants ride in the spare slots.
+// Rows of a tile are spheres: row (v & 3) + 8 (v >> 2) + 4 h holds sphere 16 h + v of the chunk,
+// so that after the products the 16 accumulator registers of a lower-half lane are spheres
+// 0..15 and those of an upper-half lane spheres 16..31 of the lane's column (= ray).
+// Two tiles cover the wave's 64 rays (ray group g = rays 32 g .. 32 g + 31); a lane owns ray
+// `lane`, so for each group one half of the lanes holds bits of rays the other half owns, and one
+// v_permlane32_swap puts them right.  What is left for the vector ALU is one v_fma_f32 and one
+// v_alignbit_b32 per accumulator register: 2 instructions per ray-sphere test instead of 5, the
+// matrix cores working beside them.
+//
+// Error: with u = 2^-24, every accumulation step of a 16-term MFMA is taken to err by at most
+// u times the sum of the magnitudes it adds (f32 accumulation, any order), i.e. |s - S| <=
+// 32u (|o| + |c|) and |t - T| <= 32u ((|o| + |c|)^2 + r^2), against 10.5u and 8u for the fma chains
+// of sieve_pair; together with the shader's own error that stays below
+// 250u (o.o + c.c) + 50u r^2, and this path uses the margin RT_SIEVE_MARGIN_MFMA = 2^-15 = 512u.
+// rt_debug_sieve_audit runs this very code on caller-supplied rays and must find no miss.
+
+// The three bf16 terms of x as f32 values whose low 16 bits are zero (x = x1 + x2 + x3 exactly
+// for finite x; terms below the bf16 normal range may be flushed by the matrix core).
+__device__ __forceinline__ void split3(float x, uint32_t& x1, uint32_t& x2, uint32_t& x3)
+{
+    x1 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(x1);
+    x2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(x2);
+    x3 = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// {lo, hi} -> one register holding bf16(lo) in its low half and bf16(hi) in its high half
+__device__ __forceinline__ uint32_t pack_bf(uint32_t lo, uint32_t hi)
+{
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// Ray-side fragment of one coordinate: elements b_q[j], q = 1 2 1 2 3 1 3 2.
+__device__ __forceinline__ v4u ray_frag(float x)
+{
+    uint32_t b1, b2, b3;
+    split3(x, b1, b2, b3);
+    const uint32_t r01 = pack_bf(b1, b2);
+    return v4u{r01, r01, pack_bf(b3, b1), pack_bf(b3, b2)};
+}
+
+// Ray-side fragment of coordinate 3: {lead x 3, c1, c2, c3, 0, 0}, lead = 0 (s-product) or 1 (t-product).
+__device__ __forceinline__ v4u ray_frag_const(float c, bool ones)
+{
+    uint32_t c1, c2, c3;
+    split3(c, c1, c2, c3);
+    const uint32_t one = ones ? 0x3f800000u : 0u;
+    return v4u{pack_bf(one, one), pack_bf(one, c1), pack_bf(c2, c3), 0u};
+}
+
+struct MfmaRay {
+    v8bf s0[2], s1[2];  // s-product, step 0 / 1, ray group 0 / 1
+    v8bf t0[2], t1[2];  // t-product
+};
+
+// Own-ray fragments of coordinates (lo, hi) -> the operands of the two ray groups for one step:
+// group 0 wants {lower lanes: own lo, upper lanes: hi of the lane 32 below}, group 1 the mirror
+// image; v_permlane32_swap exchanges the upper half of its first operand with the lower half of
+// its second.
+__device__ __forceinline__ void swap_halves(v4u lo, v4u hi, v8bf& g0, v8bf& g1)
+{
+    v4u a, b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const v2u r = __builtin_amdgcn_permlane32_swap(lo[k], hi[k], false, false);
+        a[k] = r.x;
+        b[k] = r.y;
+    }
+    g0 = __builtin_bit_cast(v8bf, a);
+    g1 = __builtin_bit_cast(v8bf, b);
+}
+
+__device__ __forceinline__ MfmaRay mfma_ray(const Path& p, float a)
+{
+    const float inv = __builtin_amdgcn_rsqf(a);  // 1 ulp is plenty: the margin absorbs it
+    const float nx = p.dx * inv, ny = p.dy * inv, nz = p.dz * inv;
+    const float d0 = __builtin_fmaf(nz, p.oz, __builtin_fmaf(ny, p.oy, nx * p.ox));
+    const float o2 = __builtin_fmaf(p.oz, p.oz, __builtin_fmaf(p.oy, p.oy, p.ox * p.ox));
+    MfmaRay r;
+    swap_halves(ray_frag(-nx), ray_frag(-ny), r.s0[0], r.s0[1]);
+    swap_halves(ray_frag(-nz), ray_frag_const(d0, false), r.s1[0], r.s1[1]);
+    swap_halves(ray_frag(2.0f * p.ox), ray_frag(2.0f * p.oy), r.t0[0], r.t0[1]);
+    swap_halves(ray_frag(2.0f * p.oz), ray_frag_const(o2 * (RT_SIEVE_MARGIN_MFMA - 1.0f), true), r.t1[0], r.t1[1]);
+    return r;
+}
+
+// Sieve of one chunk: frag points at the chunk's two steps of 64 lane fragments in LDS.  Same
+// result convention as sieve_chunk: bit (31-n) SET when sphere n of the chunk is rejected.
+__device__ __forceinline__ uint32_t sieve_chunk_mfma(const v8bf* frag, int lane, const MfmaRay& r)
+{
+    const v8bf a0 = frag[lane], a1 = frag[64 + lane];
+    uint32_t m[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const v16f zero = {0};
+        v16f S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, r.s0[g], zero, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.s1[g], S, 0, 0, 0);
+        v16f T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, r.t0[g], zero, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.t1[g], T, 0, 0, 0);
+        uint32_t mask = 0;
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(S[v], S[v], T[v])), 31);
+        m[g] = mask;  // spheres 16 h .. 16 h + 15 of ray 32 g + (lane & 31), h = lane >> 5
+    }
+    // lower lanes own group 0, upper lanes group 1: m[0] keeps its lower half and takes m[1]'s
+    // lower half (spheres 0..15 of the upper lanes' own rays) into its upper half, and so on
+    const v2u own = __builtin_amdgcn_permlane32_swap(m[0], m[1], false, false);
+    return (own.x << 16) | own.y;
+}
+
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
 // n_pad*16 B sieve geometry + n_pad*4 B radii + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
 //
@@ -576,8 +708,9 @@ typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
 template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
 {
-    constexpr bool SGEOM = MODE != 0;
+    constexpr bool SGEOM = MODE == 1 || MODE == 2;
     constexpr bool CULL = MODE == 2;
+    constexpr bool MFMA = MODE == 3;
     extern __shared__ float4 smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -589,8 +722,12 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         smem[i] = P.geom[i];
         radius[i] = P.radius[i];
     }
+    // matrix-core sieve: the sphere-side operand fragments follow (128 x 16 bytes per chunk)
+    uint4* frags = reinterpret_cast<uint4*>(radius + P.n_lds);
+    const int n_frag = MFMA ? P.n_lds * 4 : 0;
+    for (int i = threadIdx.x; i < n_frag; i += blockDim.x) frags[i] = P.frags[i];
     __syncthreads();  // the only barrier: waves run independently from here on
-    uint32_t* wmask = reinterpret_cast<uint32_t*>(radius + P.n_lds) + wave * (RT_SG_CHUNKS * 64);
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(frags + n_frag) + wave * (RT_SG_CHUNKS * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
@@ -731,7 +868,12 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
         float best = RT_FLT_MAX;
         int idx = -1;
         {
-            const SieveRay sr = sieve_ray(p, a, alive);
+            SieveRay sr;
+            MfmaRay mr;
+            if constexpr (MFMA)
+                mr = mfma_ray(p, a);
+            else
+                sr = sieve_ray(p, a, alive);
             for (int sg = 0; sg < nch; sg += RT_SG_CHUNKS) {
                 const int nsg = min(RT_SG_CHUNKS, nch - sg);
                 uint32_t summary = 0;
@@ -765,7 +907,10 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                     constexpr int PGROUP = 2;  // the ragged last chunk goes 2 pairs at a time
                     const int ngroups = (P.last_chunk_count + 2 * PGROUP - 1) / (2 * PGROUP);
                     uint32_t rej;
-                    if constexpr (CULL) {
+                    if constexpr (MFMA) {
+                        rej = sieve_chunk_mfma(reinterpret_cast<const v8bf*>(frags) + (sg + c) * 128, lane, mr);
+                        if (!alive) rej = 0xffffffffu;  // an idle lane has no candidates
+                    } else if constexpr (CULL) {
                         const uint32_t need = (uint32_t)(wneed >> (60 - 4 * c)) & 0xfu;
                         if (need == 0u) {  // nobody's candidate: the walk never reads this chunk's masks
                             summary <<= 1;
@@ -904,7 +1049,10 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
                                                             unsigned long long* out)
 {
     extern __shared__ float4 smem[];
+    const bool mfma = P.frags != nullptr;  // audit the matrix-core sieve instead
+    uint4* frags = reinterpret_cast<uint4*>(smem + P.n_pad);
     for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) smem[i] = P.geom[i];
+    for (int i = threadIdx.x; i < (mfma ? P.n_pad * 4 : 0); i += blockDim.x) frags[i] = P.frags[i];
     __syncthreads();
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = ray < n_rays;
@@ -915,8 +1063,11 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
     const float a_s = dot3<false>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
     const float a_f = dot3<true>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
     const SieveRay sr = sieve_ray(p, a_s, true);
+    const MfmaRay mr = mfma_ray(p, a_s);
     for (int ch = 0; ch < P.n_pad / RT_CHUNK; ch++) {
-        const uint32_t rej = sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
+        const uint32_t rej =
+            mfma ? sieve_chunk_mfma(reinterpret_cast<const v8bf*>(frags) + ch * 128, threadIdx.x & 63, mr)
+                 : sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
         for (int n = 0; n < RT_CHUNK; n++) {
             const int i = ch * RT_CHUNK + n;
             if (i >= P.sphere_count || !live) break;
@@ -1040,17 +1191,18 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t rt_stream_lds_bytes(int n_lds, int threads)
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma)
 {
-    return (size_t)n_lds * (sizeof(float4) + sizeof(float)) +
+    return (size_t)n_lds * (sizeof(float4) + sizeof(float) + (mfma ? 4 * sizeof(uint4) : 0)) +
            (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
 }
 
-// mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0)
+// mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
+// 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0)
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
-    size_t lds = rt_stream_lds_bytes(P.n_lds, threads);
+    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3);
     static const size_t pad = [] {
         const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
         return e ? (size_t)atol(e) : (size_t)0;
@@ -1062,6 +1214,13 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
                          : launch_stream<false, true, 2>(P, blocks, threads, lds, st);
         return fused ? launch_stream<true, false, 2>(P, blocks, threads, lds, st)
                      : launch_stream<false, false, 2>(P, blocks, threads, lds, st);
+    }
+    if (mode == 3) {
+        if (record)
+            return fused ? launch_stream<true, true, 3>(P, blocks, threads, lds, st)
+                         : launch_stream<false, true, 3>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, false, 3>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 3>(P, blocks, threads, lds, st);
     }
     if (P.n_lds == 0) mode = 1;  // nothing staged: the sieve must read global memory
     if (record && P.n_lds)  // the debug twin takes the LDS path when there is one
@@ -1110,7 +1269,7 @@ hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const fl
 hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
                                  hipStream_t st)
 {
-    const size_t lds = (size_t)P.n_pad * sizeof(float4);
+    const size_t lds = (size_t)P.n_pad * (sizeof(float4) + (P.frags ? 4 * sizeof(uint4) : 0));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_sieve_audit_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -26,6 +26,11 @@ constexpr int RT_MAX_LDS_SPHERES = RT_MAX_LDS;
 constexpr int RT_MAX_SGPR_SPHERES = 2048;
 // Relative safety margin of the sieve (2^-16 = 256 ulp): see sieve_chunk in rt_kernels.hip.
 constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
+// Margin of the sieve evaluated on the matrix cores (2^-15: see "sieve on the matrix cores" in
+// rt_kernels.hip), and the largest sphere count whose operand fragments (64 B per sphere) are
+// staged in LDS beside the rest.
+constexpr float RT_SIEVE_MARGIN_MFMA = 3.0517578125e-05f;
+constexpr int RT_MAX_MFMA_SPHERES = 1024;
 // Culled kernel: spheres per culling group, and the relative margin on o.o of the group test
 // (2^-9; see build_culled in rt_api.cpp for why it is larger than the sieve's).
 constexpr int RT_CULL_GROUP = 8;
@@ -77,6 +82,7 @@ struct RtParams {
     const RtSphereAos* spheres;  // AoS copy, read for centre/albedo of the winning sphere
     const float4* geom;          // pair-packed sieve geometry: {cx0,cx1,cy0,cy1},{cz0,cz1,w0,w1}
     const float* radius;         // radii, n_pad entries (read by the literal test of the walk)
+    const uint4* frags;          // matrix-core sieve only: per chunk 2 steps x 64 lanes x 8 bf16 sphere-side operands
     const float2* materials;     // material extension: {kind, param} per sphere; null = all kind 0
     // culled kernel only: geom/radius above are the spatially sorted copies, and
     const float4* bounds;        // pair-packed like geom: bounding sphere of every group of 8 slots,

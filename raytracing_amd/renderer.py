@@ -21,6 +21,7 @@ KERNEL_TILE = 1
 KERNEL_STREAM_SGPR = 2
 KERNEL_STREAM_LDS = 3
 KERNEL_STREAM_CULLED = 4
+KERNEL_STREAM_MFMA = 5
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1
 CLEAR_NEVER = 2
