@@ -440,7 +440,11 @@ void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* t
 bool wants_mfma(const rt_context* c, const RtParams& P)
 {
     const bool can = c->have_frags && P.n_pad > 0 && P.n_pad <= RT_MAX_MFMA_SPHERES;
-    return can && c->kernel == RT_KERNEL_STREAM_MFMA;
+    static const int min_pad = [] {
+        const char* e = getenv("RT_DEBUG_MFMA_MIN_SPHERES");  // development knob: smallest padded count RT_KERNEL_STREAM hands to the matrix cores
+        return e ? atoi(e) : 64;
+    }();
+    return can && (c->kernel == RT_KERNEL_STREAM_MFMA || (c->kernel == RT_KERNEL_STREAM && P.n_pad >= min_pad));
 }
 
 }  // namespace
@@ -455,12 +459,16 @@ void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const R
                         int* threads)
 {
     const bool mfma = P.frags != nullptr;  // the operand fragments are staged in LDS too: larger workgroups share them
-    int t = want_threads > 0 ? want_threads : (mfma ? 512 : P.n_lds <= 1024 ? 256 : 1024);
-    t = std::max(64, std::min(1024, t / 64 * 64));
+    // matrix-core sieve: two waves per SIMD saturate it (measured: 8 waves per CU = 12 = 16); 256-thread
+    // workgroups while two of them fit in LDS, else one of 512
+    const int t_mfma = rt_stream_lds_bytes(P.n_lds, 256, true) * 2 <= kLdsPerCu ? 256 : 512;
+    int t = want_threads > 0 ? want_threads : (mfma ? t_mfma : P.n_lds <= 1024 ? 256 : 1024);
+    t = std::max(64, std::min(mfma ? RT_MFMA_MAX_THREADS : 1024, t / 64 * 64));
     const size_t lds = rt_stream_lds_bytes(P.n_lds, t, mfma);
     const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
     int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)cu_count ? 8 : 12;
     if (t == 1024) waves_per_cu = 16;  // whole workgroups: one per CU
+    if (mfma) waves_per_cu = 8;
     int per_cu = std::min<int>(std::max(1, waves_per_cu / (t / 64)), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
     per_cu = std::max(1, per_cu);
     int b = want_blocks > 0 ? want_blocks : cu_count * per_cu;

@@ -688,6 +688,75 @@ __device__ __forceinline__ uint32_t sieve_chunk_mfma(const v8bf* frag, int lane,
     return (own.x << 16) | own.y;
 }
 
+// The four MFMAs of one 32 x 32 tile (ray group g of a chunk).
+__device__ __forceinline__ void mfma_tile(v8bf a0, v8bf a1, const MfmaRay& r, int g, v16f& S, v16f& T)
+{
+    const v16f zero = {0};
+    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, r.s0[g], zero, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, r.t0[g], zero, 0, 0, 0);
+    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.s1[g], S, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.t1[g], T, 0, 0, 0);
+}
+
+// Sign bits of g = s^2 + t over a tile's 16 accumulator registers, first register in bit 15.
+__device__ __forceinline__ uint32_t tile_mask(const v16f& S, const v16f& T)
+{
+    uint32_t mask = 0;
+#pragma unroll
+    for (int v = 0; v < 16; v++)
+        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(S[v], S[v], T[v])), 31);
+    return mask;
+}
+
+// Matrix-core sieve of `nsg` consecutive chunks (frag = the first one's fragments in LDS),
+// software-pipelined by one tile: the MFMAs of the next tile are issued before the vector
+// instructions that read the current tile's accumulators, so that a wave keeps both pipes busy
+// by itself.  Writes the candidate masks of the chunks to wmask[c * 64 + lane] and returns the
+// summary (bit 31 - c set when chunk c has a candidate for this lane).
+__device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg, int lane, const MfmaRay& r,
+                                                      bool alive, bool has_last, uint32_t last_valid,
+                                                      uint32_t* wmask)
+{
+    uint32_t summary = 0;
+    v16f SA, TA, SB, TB;
+    v8bf a0 = frag[lane], a1 = frag[64 + lane];
+    mfma_tile(a0, a1, r, 0, SA, TA);
+    for (int c = 0; c < nsg; c++) {
+        // the next chunk's fragments are on their way while this chunk is worked on (the last
+        // chunk "prefetches" itself: its extra tile is computed and dropped, which keeps the loop
+        // body free of branches for the instruction scheduler)
+        const int cn = min(c + 1, nsg - 1);
+        const v8bf n0 = frag[cn * 128 + lane], n1 = frag[cn * 128 + 64 + lane];
+        mfma_tile(a0, a1, r, 1, SB, TB);
+        const uint32_t m0 = tile_mask(SA, TA);
+        // one MFMA, then the eight vector instructions of four accumulator registers: the matrix
+        // pipe takes 32 cycles per MFMA, the vector instructions fit beside it
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+        mfma_tile(n0, n1, r, 0, SA, TA);
+        const uint32_t m1 = tile_mask(SB, TB);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+        a0 = n0;
+        a1 = n1;
+        // lower lanes own ray group 0, upper lanes group 1: after the swap .x holds spheres 0..15
+        // and .y spheres 16..31 of the lane's own ray
+        const v2u own = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
+        uint32_t cand = ~((own.x << 16) | own.y);
+        if (has_last && c == nsg - 1) cand &= last_valid;
+        if (!alive) cand = 0u;  // an idle lane has no candidates
+        wmask[c * 64 + lane] = cand;
+        summary = (summary << 1) | (cand != 0u ? 1u : 0u);
+    }
+    return summary << (32 - nsg);
+}
+
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
 // n_pad*16 B sieve geometry + n_pad*4 B radii + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
 //
@@ -706,7 +775,7 @@ typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
 #endif
 
 template <bool FUSED, bool RECORD, int MODE>
-__global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
+__global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : 1024) rt_stream_kernel(const RtParams P)
 {
     constexpr bool SGEOM = MODE == 1 || MODE == 2;
     constexpr bool CULL = MODE == 2;
@@ -901,40 +970,42 @@ __global__ void __launch_bounds__(1024) rt_stream_kernel(const RtParams P)
                     wneed = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)need0) << 32) |
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)need1);
                 }
-                for (int c = 0; c < nsg; c++) {
-                    constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
-                    const bool last = sg + c == nch - 1;
-                    constexpr int PGROUP = 2;  // the ragged last chunk goes 2 pairs at a time
-                    const int ngroups = (P.last_chunk_count + 2 * PGROUP - 1) / (2 * PGROUP);
-                    uint32_t rej;
-                    if constexpr (MFMA) {
-                        rej = sieve_chunk_mfma(reinterpret_cast<const v8bf*>(frags) + (sg + c) * 128, lane, mr);
-                        if (!alive) rej = 0xffffffffu;  // an idle lane has no candidates
-                    } else if constexpr (CULL) {
-                        const uint32_t need = (uint32_t)(wneed >> (60 - 4 * c)) & 0xfu;
-                        if (need == 0u) {  // nobody's candidate: the walk never reads this chunk's masks
-                            summary <<= 1;
-                            continue;
+                if constexpr (MFMA) {
+                    summary = sieve_chunks_mfma(reinterpret_cast<const v8bf*>(frags) + sg * 128, nsg, lane, mr, alive,
+                                                sg + nsg == nch, P.last_chunk_valid, wmask);
+                } else {
+                    for (int c = 0; c < nsg; c++) {
+                        constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
+                        const bool last = sg + c == nch - 1;
+                        constexpr int PGROUP = 2;  // the ragged last chunk goes 2 pairs at a time
+                        const int ngroups = (P.last_chunk_count + 2 * PGROUP - 1) / (2 * PGROUP);
+                        uint32_t rej;
+                        if constexpr (CULL) {
+                            const uint32_t need = (uint32_t)(wneed >> (60 - 4 * c)) & 0xfu;
+                            if (need == 0u) {  // nobody's candidate: the walk never reads this chunk's masks
+                                summary <<= 1;
+                                continue;
+                            }
+                            ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
+                            rej = sieve_chunk_culled(g, sr, need);
+                        } else if constexpr (SGEOM) {
+                            ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
+                            rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
+                                                                         : sieve_chunk<GROUP>(g, sr);
+                        } else {
+                            const v4f* g = reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK;
+                            rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
+                                                                         : sieve_chunk<GROUP>(g, sr);
                         }
-                        ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
-                        rej = sieve_chunk_culled(g, sr, need);
-                    } else if constexpr (SGEOM) {
-                        ConstGeomPtr g = (ConstGeomPtr)(const void*)(P.geom) + (sg + c) * RT_CHUNK;
-                        rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
-                                                                     : sieve_chunk<GROUP>(g, sr);
-                    } else {
-                        const v4f* g = reinterpret_cast<const v4f*>(smem) + (sg + c) * RT_CHUNK;
-                        rej = last && ngroups < RT_CHUNK / 2 / PGROUP ? sieve_chunk_partial<PGROUP>(g, sr, ngroups)
-                                                                     : sieve_chunk<GROUP>(g, sr);
+                        // Idle lanes carry -inf in the sieve constants and reject everything through
+                        // the arithmetic; only the last chunk has spheres beyond sphere_count to mask.
+                        uint32_t cand = ~rej;
+                        if (last) cand &= P.last_chunk_valid;
+                        wmask[c * 64 + lane] = cand;
+                        summary = (summary << 1) | (cand != 0u ? 1u : 0u);
                     }
-                    // Idle lanes carry -inf in the sieve constants and reject everything through
-                    // the arithmetic; only the last chunk has spheres beyond sphere_count to mask.
-                    uint32_t cand = ~rej;
-                    if (last) cand &= P.last_chunk_valid;
-                    wmask[c * 64 + lane] = cand;
-                    summary = (summary << 1) | (cand != 0u ? 1u : 0u);
+                    summary <<= (32 - nsg);
                 }
-                summary <<= (32 - nsg);
                 RT_MARK(t_sieve)
                 // walk: every lane visits its own candidates in increasing sphere index
                 uint32_t cur = 0;

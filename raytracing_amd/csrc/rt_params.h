@@ -31,6 +31,11 @@ constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
 // staged in LDS beside the rest.
 constexpr float RT_SIEVE_MARGIN_MFMA = 3.0517578125e-05f;
 constexpr int RT_MAX_MFMA_SPHERES = 1024;
+// Largest workgroup of the matrix-core instantiation: its operand fragments and accumulators want
+// more registers than 1024-thread workgroups (4 waves per SIMD, 128 registers) leave.
+#ifndef RT_MFMA_MAX_THREADS
+#define RT_MFMA_MAX_THREADS 768
+#endif
 // Culled kernel: spheres per culling group, and the relative margin on o.o of the group test
 // (2^-9; see build_culled in rt_api.cpp for why it is larger than the sieve's).
 constexpr int RT_CULL_GROUP = 8;

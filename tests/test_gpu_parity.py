@@ -17,7 +17,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 PROFILES = [("strict", 0), ("fused", 1)]
-KERNELS = [("stream", 0), ("tile", 1), ("stream_sgpr", 2), ("stream_lds", 3)]
+KERNELS = [("stream", 0), ("tile", 1), ("stream_sgpr", 2), ("stream_lds", 3), ("stream_mfma", 5)]
 
 
 def _bits(a):
@@ -130,19 +130,30 @@ def _tangent_rays(spheres, origins, rng, per_origin):
     return rays.astype(np.float32)
 
 
-@pytest.mark.parametrize("scene_name", ["default", "rtiow", "cube1000"])
-def test_sieve_never_rejects_a_literal_candidate(rt, default_scene, rtiow_scene, scene_name):
+@pytest.mark.parametrize("sieve,kernel", [("vector", 2), ("matrix", 5)])
+@pytest.mark.parametrize("scene_name", ["default", "rtiow", "cube1000", "far"])
+def test_sieve_never_rejects_a_literal_candidate(rt, default_scene, rtiow_scene, scene_name, sieve, kernel):
     """The stream kernel rejects spheres with a cheap conservative test before it evaluates the
-    shader's expressions.  Audit it directly: on random, camera-like and limb-grazing rays no
-    sphere with a non-negative literal discriminant (either float profile) may be rejected, and
-    the sieve must still reject nearly everything the literal test rejects."""
-    scene = {"default": default_scene, "rtiow": rtiow_scene}.get(scene_name) or rt.Scene.generate(rt.KIND_CUBE, 1000, 5)
+    shader's expressions: on the vector ALU (fma chains) or on the matrix cores (bf16-split
+    operands).  Audit both directly: on random, camera-like and limb-grazing rays no sphere with
+    a non-negative literal discriminant (either float profile) may be rejected, and the sieve
+    must still reject nearly everything the literal test rejects.  "far" is the default scene
+    moved 3000 units from the origin, where the expanded form cancels hardest."""
+    scene = {"default": default_scene, "rtiow": rtiow_scene}.get(scene_name)
+    if scene_name == "cube1000":
+        scene = rt.Scene.generate(rt.KIND_CUBE, 1000, 5)
+    if scene_name == "far":
+        scene = rt.Scene.default()
+        shift = np.array([3000.0, -1700.0, 2500.0], np.float32)
+        scene.spheres["center"] += shift
+        scene.camera["camera_position"][0] += shift
     sph = scene.spheres[: scene.sphere_count]
     rng = np.random.default_rng(42)
     cam = scene.camera["camera_position"][0].astype(np.float64)
     lo = sph["center"].min(0) - 5.0
     hi = sph["center"].max(0) + 5.0
-    lo, hi = np.maximum(lo, -60.0), np.minimum(hi, 60.0)
+    if scene_name != "far":
+        lo, hi = np.maximum(lo, -60.0), np.minimum(hi, 60.0)
     # origins: the camera, points in the scene's box, points on sphere surfaces (bounce origins)
     k = rng.integers(0, len(sph), 600)
     n = rng.standard_normal((600, 3))
@@ -155,13 +166,16 @@ def test_sieve_never_rejects_a_literal_candidate(rt, default_scene, rtiow_scene,
     rays.append(np.concatenate([o, d], axis=1).astype(np.float32))
     rays = np.concatenate(rays)
     with rt.Renderer(64, 64) as r:
+        r.set_kernel(kernel)
         r.upload_spheres(scene.spheres)
         r.set_uniforms(scene.camera)
         res = r.sieve_audit(rays)
     assert res["missed_strict"] == 0 and res["missed_fused"] == 0, res
     assert res["exact"] > 10000
-    # limb-grazing rays are over-represented here; even so few needless candidates pass
-    assert res["passed"] <= 1.25 * res["exact"] + 1000, res
+    # limb-grazing rays are over-represented here; even so few needless candidates pass (far from
+    # the origin the margin, which scales with the squared distance from it, lets more through)
+    slack = {"vector": 1.25, "matrix": 1.35}[sieve] if scene_name != "far" else 60.0
+    assert res["passed"] <= slack * res["exact"] + 1000, res
 
 
 # ---------------------------------------------------------------- records: hashes + hit indices

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweep the stream kernel's launch geometry on one GPU (development aid).
 
-usage: python tools/launch_sweep.py [scene=rtiow|default|cubeN] [W H] [frames]
+usage: python tools/launch_sweep.py [scene=rtiow|default|cubeN] [W H] [frames] [kernels=2,3] [threads=64,...]
 """
 import os
 import sys
@@ -17,6 +17,8 @@ def main():
     w = int(a[1]) if len(a) > 1 else 3840
     h = int(a[2]) if len(a) > 2 else 2160
     frames = int(a[3]) if len(a) > 3 else 8
+    kernels = [int(k) for k in a[4].split(",")] if len(a) > 4 else [2, 3]
+    thread_list = [int(k) for k in a[5].split(",")] if len(a) > 5 else [64, 128, 256, 512, 1024]
     if name == "rtiow":
         scene = rt.Scene.generate(rt.KIND_RTIOW, 0, 7)
     elif name == "default":
@@ -29,9 +31,9 @@ def main():
         r.upload_spheres(scene.spheres)
         r.set_uniforms(ubo)
         cus = r.info()["cu_count"]
-        for kernel in (2, 3):
-            for threads in (64, 128, 256, 512, 1024):
-                for waves_per_cu in (8, 12, 16, 20, 24, 28, 32):
+        for kernel in kernels:
+            for threads in thread_list:
+                for waves_per_cu in (4, 6, 8, 12, 16, 20, 24, 28, 32):
                     blocks = cus * waves_per_cu * 64 // threads
                     if blocks * threads // cus != waves_per_cu * 64:
                         continue
