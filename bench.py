@@ -43,6 +43,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_TEST = 21             # algorithmic FP32 flop per ray-sphere test (a hoisted)
 PEAK_FP32_TFLOPS = 157.3       # MI355X FP32 vector peak
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak
+MFMA_FLOP_PER_TEST = 128       # executed on the matrix cores per test: 4 MFMAs of 32x32x16 per 32x32 tests
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
 BYTES_PER_PIXEL_DISPATCH = 36  # float4 read + float4 write + rgba8 write
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
@@ -69,9 +71,10 @@ def parse_args():
     p.add_argument("--workload", choices=list(WORKLOADS), default="rtiow4k")
     p.add_argument("--frames-per-step", type=int, default=None)
     p.add_argument("--profile", choices=["strict", "fused"], default="strict")
-    p.add_argument("--kernel", choices=["stream", "tile", "culled"], default="stream",
-                   help="stream: the brute-force kernel the metrics are quoted on; culled: the same kernel over a "
-                        "spatially sorted sphere list, skipping groups no ray of a wave can touch (same image)")
+    p.add_argument("--kernel", choices=["stream", "valu", "tile", "culled"], default="stream",
+                   help="stream: the brute-force kernel the metrics are quoted on (sieve on the matrix cores from 33 to "
+                        "1024 spheres); valu: the same with the sieve on the vector ALU; culled: over a spatially sorted "
+                        "sphere list, skipping groups no ray of a wave can touch (same image)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--max-depth", type=int, default=None)
     p.add_argument("--materials", action="store_true",
@@ -185,7 +188,7 @@ def pmc_record(key):
         return None
 
 
-def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key):
+def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key, sieve_mode):
     """Algorithmic FP32 work and HBM bytes of the average launch against the two roofs."""
     launch_ms = kernel_ms / max(1, launches)
     achieved = tests / max(1, launches) * FLOP_PER_TEST / (launch_ms * 1e-3) / 1e12
@@ -209,9 +212,19 @@ def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key):
                            "passes of this command, FETCH_SIZE doubled (gfx950), collected separately, not in this run")
                           if pmc.get("traffic_bytes_per_launch") is not None else None,
     }
-    for k in ("valu_busy", "executed_flop_frac", "clock_ghz", "valu_insts_per_launch"):
+    for k in ("valu_busy", "mfma_busy", "executed_flop_frac", "clock_ghz", "valu_insts_per_launch"):
         if k in pmc:
             out[k] = pmc[k]
+    if sieve_mode == 3:
+        executed = tests / max(1, launches) * MFMA_FLOP_PER_TEST / (launch_ms * 1e-3) / 1e12
+        out["bound"] = "mfma"
+        out["bound_detail"] = ("the sieve's two K=4 dot products (rays x spheres) run on the matrix cores as exact three-term "
+                               "bf16 splits (v_mfma_f32_32x32x16_bf16, 128 executed flop per test), the vector ALU keeps 2 "
+                               "instructions per test; `achieved`/`frac` stay the ALGORITHMIC FP32 work (21 flop per test) "
+                               "against the FP32 peak (vector = dense FP32 MFMA = 157.3 TFLOP/s) and may exceed 1 because "
+                               "the split products run at the bf16 rate; `matrix_pipe` prices what is executed")
+        out["matrix_pipe"] = {"achieved": executed, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (bf16, executed)",
+                              "frac": executed / PEAK_BF16_TFLOPS, "flop_per_test": MFMA_FLOP_PER_TEST}
     if args.kernel == "culled":
         # whole groups of spheres are skipped: rays x sphereCount counts tests that were never made
         out["achieved"] = out["frac"] = None
@@ -229,7 +242,8 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
     w, h = wl["size"]
     scene, scene_text = make_scene(rt, wl["scene"], args.materials)
     profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
-    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED}.get(args.kernel, rt.KERNEL_STREAM)
+    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED,
+              "valu": rt.KERNEL_STREAM_SGPR}.get(args.kernel, rt.KERNEL_STREAM)
     fps = args.frames_per_step
 
     split = SampleSplit(rank, world)
@@ -308,7 +322,7 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
             },
             "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
             "roofline": roofline(args, cnt["sphere_tests"], launches, kernel_ms, (w // 8 * 8) * (h // 8 * 8),
-                                 f"{args.workload}_{args.kernel}_{args.profile}"),
+                                 f"{args.workload}_{args.kernel}_{args.profile}", r.sieve_mode()),
         }
         if args.cpu_seconds > 0 and world == 1:  # the CPU leg runs at N=1 only
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds)
@@ -402,7 +416,7 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
             "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
             # the slowest rank's kernel time over its launches; tests and pixels of that band
             "roofline": roofline(args, cnt["sphere_tests"], launches, kernel_ms, (w // 8 * 8) * band_rows,
-                                 f"interactive_{args.kernel}_{args.profile}"),
+                                 f"interactive_{args.kernel}_{args.profile}", r.sieve_mode()),
         }
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds,

@@ -48,18 +48,20 @@ enum {
 /* Which kernel runs a dispatch.  All give bit-identical images. */
 enum {
     RT_KERNEL_STREAM = 0, /* persistent waves; a lane whose path ends takes the next pixel;
-                             picks one of the two geometry sources below by sphere count      */
+                             picks the sieve (matrix cores or one of the two vector-ALU
+                             variants below) by sphere count                                   */
     RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
     RT_KERNEL_STREAM_SGPR = 2, /* STREAM, sieve geometry read through the scalar cache (SGPRs) */
     RT_KERNEL_STREAM_LDS = 3,  /* STREAM, sieve geometry read from the LDS copy                */
-    RT_KERNEL_STREAM_MFMA = 5, /* STREAM with the sieve's two dot products (rays x spheres, K = 4) evaluated by the
-                                  matrix cores on exact three-term bf16 splits of the f32 operands; the vector
-                                  ALU keeps 2 instructions per test.  Up to 1024 traced spheres, else STREAM. */
-    RT_KERNEL_STREAM_CULLED = 4 /* STREAM over a spatially sorted copy of the sphere list: groups of 8
+    RT_KERNEL_STREAM_CULLED = 4, /* STREAM over a spatially sorted copy of the sphere list: groups of 8
                                   spheres whose bounding sphere no ray of the wave can touch are
                                   skipped.  Not brute force any more (the step the reference's
                                   readme.md:38 names, a spatial hierarchy); same bits.  Scenes of fewer
                                   than 97 or more than 4096 traced spheres run RT_KERNEL_STREAM.    */
+    RT_KERNEL_STREAM_MFMA = 5  /* STREAM with the sieve's two dot products (rays x spheres, K = 4) evaluated by the
+                                  matrix cores on exact three-term bf16 splits of the f32 operands; the vector
+                                  ALU keeps 2 instructions per test.  RT_KERNEL_STREAM picks it by itself from
+                                  33 to 1024 traced spheres; this value forces it from 1 sphere on. */
 };
 
 /* When the accumulation texel is zeroed. */
@@ -193,6 +195,11 @@ int rt_timed_total(rt_context* ctx, float* ms, int* dispatches);
    counterpart: the shader's is fixed at local_size 8x8 (res/shaders/shader.comp:2). */
 int rt_set_launch(rt_context* ctx, int blocks, int threads_per_block);
 int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* threads);
+/* Where the last stream-kernel dispatch evaluated its sieve: 0 vector ALU with geometry from LDS,
+   1 vector ALU with geometry through the scalar cache, 2 the culled variant, 3 the matrix cores;
+   -1 when the last dispatch ran the tile kernel or nothing has been dispatched.  No reference
+   counterpart. */
+int rt_get_sieve_mode(rt_context* ctx, int* mode);
 
 /* Test hook: out[i] = op(a[i], b[i], c[i]) evaluated on the device with the kernels'
    compile flags, so the parity tests can pin the GPU's float semantics against the

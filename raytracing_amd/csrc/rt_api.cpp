@@ -90,6 +90,7 @@ struct rt_context {
     int cull_count = -1;          // sphere_count the sorted copy was built for; -1 = none / stale
 
     int last_blocks = 0, last_threads = 0; // geometry of the last stream-kernel launch
+    int last_mode = -1;                    // and its sieve: 0 LDS, 1 scalar cache, 2 culled, 3 matrix cores; -1 none yet / tile kernel
     unsigned* d_work = nullptr;           // RT_WORK_BYTES: span counters + finished-workgroup count
     unsigned long long* d_rays = nullptr; // RT_RAY_BYTES: ray counters, summed by rt_get_counters
     uint64_t paths = 0;
@@ -549,6 +550,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     const bool tile = c->kernel == RT_KERNEL_TILE;
     if (tile) {
         HIP_TRY(rt_launch_tile(P, fused, record, c->stream));
+        c->last_mode = -1;
         return RT_OK;
     }
     const bool mfma = wants_mfma(c, P);
@@ -588,6 +590,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     }
     c->last_blocks = blocks;
     c->last_threads = threads;
+    c->last_mode = mode;
     return RT_OK;
 }
 
@@ -855,6 +858,13 @@ int rt_get_info(rt_context* c, int* device, int* cu_count, int* blocks, int* thr
     if (b == 0 && c->have_ubo && make_params(c, 1, &P) == RT_OK) stream_geometry(c, P, &b, &t);
     if (blocks) *blocks = b;
     if (threads) *threads = t;
+    return RT_OK;
+}
+
+int rt_get_sieve_mode(rt_context* c, int* mode)
+{
+    if (!c || !mode) return fail(RT_E_INVALID, "null argument");
+    *mode = c->last_mode;
     return RT_OK;
 }
 

@@ -189,6 +189,12 @@ class Renderer:
         N.check(N.lib().rt_get_info(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("device", "cu_count", "blocks", "threads"), (int(x.value) for x in v)))
 
+    def sieve_mode(self) -> int:
+        """Sieve of the last stream-kernel dispatch: 0/1 vector ALU, 2 culled, 3 matrix cores, -1 none."""
+        m = C.c_int()
+        N.check(N.lib().rt_get_sieve_mode(self._h, C.byref(m)))
+        return int(m.value)
+
     def sieve_audit(self, rays: np.ndarray) -> dict:
         """rays: (n, 6) float32 origin+direction; see rt_debug_sieve_audit in include/rt_hip.h."""
         arr = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

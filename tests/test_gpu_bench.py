@@ -26,7 +26,12 @@ def _check_roofline(line, culled=False):
     roof = line["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm"} <= set(roof)
     if not culled:
-        assert 0.0 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+        # the algorithmic FP32 fraction may pass 1 once the contraction runs on the matrix cores
+        assert 0.0 < roof["frac"] < (1.0 if roof["bound"] == "valu" else 3.0)
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    if roof["bound"] == "mfma":
+        mp = roof["matrix_pipe"]
+        assert 0.0 < mp["frac"] < 1.0 and abs(mp["frac"] - mp["achieved"] / mp["peak"]) < 1e-9
     hbm = roof["hbm"]
     assert hbm["unit"] == "GB/s" and 0.0 < hbm["frac"] < 1.0 and abs(hbm["frac"] - hbm["achieved"] / hbm["peak"]) < 1e-9
     assert roof["launches"] == line["steps"] and roof["kernel_ms_per_launch"] > 0

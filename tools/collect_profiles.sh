@@ -23,7 +23,7 @@ timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU S
     --output-format csv -d "$out/pmc_sq" -o bench -- \
     python3 bench.py $args > "$out/bench_sq.log" 2>&1
 timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA \
-    SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 \
+    SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS \
     --output-format csv -d "$out/pmc_wait" -o bench -- \
     python3 bench.py $args > "$out/bench_wait.log" 2>&1 || echo "wait pass failed (optional)"
 # the unprofiled line of the same command, for the record next to the profiled one

@@ -87,10 +87,17 @@ def one(tag, wl, pmc_all):
             out["valu_busy"] = 4.0 * counters["SQ_ACTIVE_INST_VALU"] / N_SIMD / cyc
         if "SQ_INSTS_VALU" in counters:
             out["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"]
-    tests_per_launch = line["roofline"]["achieved"] * 1e12 * line["roofline"]["kernel_ms_per_launch"] * 1e-3 / line["roofline"]["flop_per_test"]
-    out["executed_flop_frac"] = (tests_per_launch * EXECUTED_FLOP_PER_TEST / (line["roofline"]["kernel_ms_per_launch"] * 1e-3)
-                                 / 1e12 / PEAK_TFLOPS)
-    out["executed_flop_note"] = "sieve only: 15 FP32 flop executed per ray-sphere test (7 v_pk_fma_f32 + 1 v_pk_add_f32 per sphere pair)"
+        if counters.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            # cycles, summed over the SIMDs, in which the matrix pipe works (32 per v_mfma_f32_32x32x16_bf16)
+            out["mfma_busy"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (durations["SQ_VALU_MFMA_BUSY_CYCLES"] * out["clock_ghz"])
+            out["mfma_insts_per_launch"] = counters.get("SQ_INSTS_MFMA")
+    if line["roofline"]["bound"] == "valu":
+        tests_per_launch = (line["roofline"]["achieved"] * 1e12 * line["roofline"]["kernel_ms_per_launch"] * 1e-3
+                            / line["roofline"]["flop_per_test"])
+        out["executed_flop_frac"] = (tests_per_launch * EXECUTED_FLOP_PER_TEST / (line["roofline"]["kernel_ms_per_launch"] * 1e-3)
+                                     / 1e12 / PEAK_TFLOPS)
+        out["executed_flop_note"] = ("sieve on the vector ALU only: 15 FP32 flop executed per ray-sphere test "
+                                     "(7 v_pk_fma_f32 + 1 v_pk_add_f32 per sphere pair)")
     out["kernel_ms_per_launch_rocprof_stats"] = None
     for r in csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))):
         if any(k in r["Name"] for k in KERNELS):
