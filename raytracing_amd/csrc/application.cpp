@@ -2,7 +2,9 @@
 #include "application.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <fstream>
+#include <limits>
 #include <sstream>
 
 namespace rt {
@@ -70,6 +72,32 @@ void Application::loadScript(const std::string& path)
         } else if (what == "resize") {
             e.kind = InputEvent::Resize;
             if (!(in >> e.width >> e.height) || e.width == 0 || e.height == 0) bad("expected: resize <w> <h>");
+        } else if (what == "ui") {
+            std::string widget;
+            if (!(in >> widget)) bad("expected: ui <reset|camera|sphere> ...");
+            auto slider = [&](float& v) {
+                std::string tok;
+                if (!(in >> tok)) return false;
+                if (tok == "=") {
+                    v = std::numeric_limits<float>::quiet_NaN();
+                    return true;
+                }
+                char* end = nullptr;
+                v = std::strtof(tok.c_str(), &end);
+                return end != tok.c_str() && *end == 0;
+            };
+            if (widget == "reset") {
+                e.kind = InputEvent::UiReset;
+            } else if (widget == "camera") {
+                e.kind = InputEvent::UiCamera;
+                if (!slider(e.value[0]) || !slider(e.value[1]) || !slider(e.value[2])) bad("expected: ui camera <x> <y> <z>");
+            } else if (widget == "sphere") {
+                e.kind = InputEvent::UiSphere;
+                if (!(in >> e.index) || !slider(e.value[0]) || !slider(e.value[1]) || !slider(e.value[2]))
+                    bad("expected: ui sphere <index> <x> <y> <z>");
+            } else {
+                bad("unknown ui widget");
+            }
         } else if (what == "quit") {
             e.kind = InputEvent::Quit;
         } else {
@@ -102,6 +130,15 @@ void Application::handleInput()
             case InputEvent::KeyUp: m_keys[(unsigned char)e.key] = false; break;
             case InputEvent::Reload: m_scene.reloadScene(); break;  // src/application.cpp:39-41
             case InputEvent::Quit: m_quit = true; break;
+            // the overlay's widgets: queued here, applied by GraphicsPipeline::render after this
+            // frame's dispatch (src/engine/engine.cpp:67-68)
+            case InputEvent::UiReset: _engine->graphicsPipeline().pressReset(); break;
+            case InputEvent::UiCamera:
+                _engine->graphicsPipeline().dragCamera(e.value[0], e.value[1], e.value[2]);
+                break;
+            case InputEvent::UiSphere:
+                _engine->graphicsPipeline().dragSphere(e.index, e.value[0], e.value[1], e.value[2]);
+                break;
             case InputEvent::Resize:
                 _engine->setFramebufferSize(e.width, e.height);
                 _engine->setFramebufferResized(true);

@@ -17,12 +17,16 @@ namespace rt {
 
 // One scripted input change, applied at the start of frame `frame` (0-based).
 struct InputEvent {
-    enum Kind { KeyDown, KeyUp, MouseDrag, Reload, Resize, Quit };
+    enum Kind { KeyDown, KeyUp, MouseDrag, Reload, Resize, Quit, UiReset, UiCamera, UiSphere };
     uint32_t frame = 0;
     Kind kind = Quit;
     char key = 0;        // KeyDown/KeyUp: one of W A S D Q E (src/application.cpp:44-67)
     float dx = 0, dy = 0;  // MouseDrag: cursor delta in pixels (src/application.cpp:85-88)
     uint32_t width = 0, height = 0;  // Resize
+    // UiCamera / UiSphere: the slider values of the settings window (NaN = slider not touched);
+    // UiSphere: index = the "Object number" (src/engine/src/graphics_pipeline.cpp:92-121)
+    uint32_t index = 0;
+    float value[3] = {0, 0, 0};
 };
 
 class Application {
@@ -36,6 +40,10 @@ class Application {
     //   <frame> mouse <dx> <dy>
     //   <frame> reload | quit
     //   <frame> resize <width> <height>
+    //   <frame> ui reset                          the settings window's "Reset frame count" button
+    //   <frame> ui camera <x> <y> <z>             its camera sliders; '=' leaves a slider alone
+    //   <frame> ui sphere <i> <x> <y> <z>         the centre sliders of "Object number i"
+    // (the ui events act after the frame's dispatch, as the overlay does, and show one frame later)
     void loadScript(const std::string& path);
     void setScript(std::vector<InputEvent> events);
 

@@ -80,6 +80,43 @@ void ComputePipeline::windowResized(uint32_t width, uint32_t height)
     m_scene.resetFrameCount();
 }
 
+// ----------------------------------------------------------- GraphicsPipeline
+
+void GraphicsPipeline::pressReset() { m_pending.push_back({0, 0, {0.f, 0.f, 0.f}}); }
+
+void GraphicsPipeline::dragCamera(float x, float y, float z) { m_pending.push_back({1, 0, {x, y, z}}); }
+
+void GraphicsPipeline::dragSphere(uint32_t index, float x, float y, float z)
+{
+    m_pending.push_back({2, index, {x, y, z}});
+}
+
+void GraphicsPipeline::render(uint32_t /*imageIndex*/, uint32_t /*currentFrame*/)
+{
+    auto slide = [](float& value, float to, float lo, float hi) {
+        if (to != to) return;  // NaN: this slider is not touched
+        value = to < lo ? lo : to > hi ? hi : to;
+    };
+    for (const Action& a : m_pending) {
+        if (a.kind == 0) {
+            m_scene.m_camera.frameCount = 0;
+        } else if (a.kind == 1) {
+            const vec3 old = m_scene.m_camera.camera_position;
+            vec3& p = m_scene.m_camera.camera_position;
+            slide(p.x, a.v[0], -100.0f, 100.0f);
+            slide(p.y, a.v[1], -100.0f, 100.0f);
+            slide(p.z, a.v[2], -100.0f, 100.0f);
+            if (old.x != p.x || old.y != p.y || old.z != p.z) m_scene.m_camera.frameCount = 0;
+        } else if (a.index < m_scene.m_spheres.size()) {
+            vec3& c = m_scene.m_spheres[a.index].center;
+            slide(c.x, a.v[0], -10.0f, 10.0f);
+            slide(c.y, a.v[1], -10.0f, 10.0f);
+            slide(c.z, a.v[2], -10.0f, 10.0f);
+        }
+    }
+    m_pending.clear();
+}
+
 // --------------------------------------------------------------------- Engine
 
 Engine::Engine(uint32_t width, uint32_t height, void* window, Scene& scene)
@@ -88,6 +125,7 @@ Engine::Engine(uint32_t width, uint32_t height, void* window, Scene& scene)
     if (window != nullptr)
         throw std::runtime_error("this build is headless: Engine accepts only a null window");
     m_computePipeline = new ComputePipeline(envInt("RT_DEVICE", 0), width, height, scene);
+    m_graphicsPipeline = new GraphicsPipeline(scene);
 }
 
 Engine::~Engine()
@@ -96,11 +134,13 @@ Engine::~Engine()
         rt_sync(m_computePipeline->context());
         delete m_computePipeline;
     }
+    delete m_graphicsPipeline;
 }
 
 void Engine::render()
 {
     m_computePipeline->render(0, m_currentFrame);
+    m_graphicsPipeline->render(0, m_currentFrame);  // engine.cpp:68: after the scene went to the device
     if (m_framebufferResized) {  // engine.cpp:123-127
         m_framebufferResized = false;
         m_computePipeline->windowResized(m_pendingWidth, m_pendingHeight);

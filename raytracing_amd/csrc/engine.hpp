@@ -46,6 +46,35 @@ class ComputePipeline {
     bool m_haveUpload = false;
 };
 
+// The part of the reference's GraphicsPipeline that reaches the kernel: its ImGui settings window
+// (src/engine/src/graphics_pipeline.cpp:83-123) mutates the scene AFTER the compute pipeline has
+// copied it for the current frame (src/engine/engine.cpp:67-68), so every change shows from the
+// next frame on.  Here the widgets are operated by queued actions instead of a mouse; nothing is
+// drawn.
+class GraphicsPipeline {
+   public:
+    explicit GraphicsPipeline(Scene& scene) : m_scene(scene) {}
+    // "Reset frame count" button (graphics_pipeline.cpp:92-94).
+    void pressReset();
+    // camera.x/y/z sliders (:95-105): range [-100, 100]; a NaN leaves that slider alone.  The frame
+    // count is reset when a value actually changes.
+    void dragCamera(float x, float y, float z);
+    // sphere.x/y/z sliders of "Object number i" (:107-121): range [-10, 10]; NaN leaves a slider
+    // alone.  The frame count is NOT reset: the image keeps accumulating over the moved sphere.
+    void dragSphere(uint32_t index, float x, float y, float z);
+    // Applies the queued actions in order (graphics_pipeline.cpp:76-134 without the drawing).
+    void render(uint32_t imageIndex, uint32_t currentFrame);
+
+   private:
+    struct Action {
+        int kind;  // 0 reset, 1 camera, 2 sphere
+        uint32_t index;
+        float v[3];
+    };
+    Scene& m_scene;
+    std::vector<Action> m_pending;
+};
+
 class Engine {
    public:
     // `window` is the reference's GLFWwindow*; only nullptr (headless) is supported.
@@ -61,9 +90,11 @@ class Engine {
     std::vector<float> readAccumulation();                     // rgba32f, width*height*4
     void writePPM(const std::string& path);                    // the colour image as binary PPM
     ComputePipeline& computePipeline() { return *m_computePipeline; }
+    GraphicsPipeline& graphicsPipeline() { return *m_graphicsPipeline; }
 
    private:
     ComputePipeline* m_computePipeline = nullptr;
+    GraphicsPipeline* m_graphicsPipeline = nullptr;
     bool m_framebufferResized = false;
     uint32_t m_pendingWidth, m_pendingHeight;
     uint32_t m_currentFrame = 0;

@@ -38,8 +38,10 @@ def _simulate(script, frames, w, h, dt=np.float32(1.0 / 60.0)):
     accum = np.zeros((h, w, 4), np.float32)
     color = None
     counts = []
+    spheres = scene.spheres.copy()
     for frame in range(frames):
         resized = None
+        ui = []
         for ev in [e for e in script if e[0] == frame]:
             if ev[1] == "key":
                 (keys.add if ev[3] == "down" else keys.discard)(ev[2])
@@ -51,6 +53,8 @@ def _simulate(script, frames, w, h, dt=np.float32(1.0 / 60.0)):
                 ubo["frameCount"][0] = 0
             elif ev[1] == "resize":
                 resized = (ev[2], ev[3])
+            elif ev[1] == "ui":
+                ui.append(ev[2:])
         speed = np.float32(100.0)
         for key, vec, sign in (("W", "camera_forward", 1), ("S", "camera_forward", -1), ("A", "camera_right", -1),
                                ("D", "camera_right", 1), ("E", "camera_up", -1), ("Q", "camera_up", 1)):
@@ -58,7 +62,23 @@ def _simulate(script, frames, w, h, dt=np.float32(1.0 / 60.0)):
                 acc += np.float32(sign) * (ubo[vec][0] * speed)
         O.scene_update(ubo, acc, vel, float(dt))
         counts.append(int(ubo["frameCount"][0]))
-        accum, color, _ = O.render(ubo, scene.spheres, w, h, n_frames=1, accum=accum, threads=8)
+        accum, color, _ = O.render(ubo, spheres, w, h, n_frames=1, accum=accum, threads=8)
+        # the overlay's widgets act after this frame's dispatch (src/engine/engine.cpp:67-68,
+        # src/engine/src/graphics_pipeline.cpp:92-121)
+        for act in ui:
+            if act[0] == "reset":
+                ubo["frameCount"][0] = 0
+            elif act[0] == "camera":
+                old = ubo["camera_position"][0].copy()
+                for k, v in enumerate(act[1:4]):
+                    if v != "=":
+                        ubo["camera_position"][0][k] = np.clip(np.float32(v), -100.0, 100.0)
+                if not np.array_equal(old, ubo["camera_position"][0]):
+                    ubo["frameCount"][0] = 0
+            elif act[0] == "sphere":
+                for k, v in enumerate(act[2:5]):
+                    if v != "=":
+                        spheres["center"][act[1]][k] = np.clip(np.float32(v), -10.0, 10.0)
         if resized:  # Engine::render: the resize takes effect after this frame's dispatch
             w, h = resized
             accum = np.zeros((h, w, 4), np.float32)
@@ -86,6 +106,32 @@ def test_headless_session_matches_reenactment(tmp_path):
     assert np.array_equal(got, color[..., :3])
     assert f"accumulated frame count {counts[-1]}" in res.stdout
     assert 1 in counts[1:9] and counts[-1] >= 1
+
+
+def test_headless_overlay_widgets_act_one_frame_late(tmp_path):
+    """The settings window's widgets as script events: the reset button and the camera sliders
+    restart the accumulation, the sphere sliders move a sphere WITHOUT restarting it
+    (src/engine/src/graphics_pipeline.cpp:92-121), and all of them act after the frame's dispatch."""
+    script = [(2, "ui", "sphere", 5, 1.5, "=", -2.25), (4, "ui", "reset"), (6, "ui", "camera", "=", 7.5, "="),
+              (7, "ui", "camera", "=", 7.5, "="),  # unchanged value: no reset
+              (8, "ui", "sphere", 0, 250.0, "=", "="),  # slider range: clamps to 10
+              (9, "ui", "camera", -500.0, "=", "=")]
+    path = tmp_path / "ui.txt"
+    with open(path, "w") as f:
+        for ev in script:
+            f.write(" ".join(str(x) for x in ev) + "\n")
+    out = tmp_path / "out.ppm"
+    env = dict(os.environ, RT_SCENE=rt.DEFAULT_SCENE)
+    for frames in (4, 6, 12):  # before / after the reset, and the whole session
+        res = subprocess.run([BINARY, "--size", "192x112", "--frames", str(frames), "--script", str(path), "--out", str(out)],
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        color, counts = _simulate(script, frames, 192, 112)
+        assert np.array_equal(_read_ppm(out), color[..., :3]), frames
+        assert f"accumulated frame count {counts[-1]}" in res.stdout
+    # frame counts seen by the kernel: the sphere edit at frame 2 does not restart them, the button
+    # at frame 4 shows at frame 5, the camera slider at 6 shows at 7, the repeated value does not reset
+    assert counts == [1, 2, 3, 4, 5, 1, 2, 1, 2, 3, 1, 2]
 
 
 def test_headless_reports_errors_like_the_reference(tmp_path):
