@@ -58,10 +58,16 @@ enum {
                                   skipped.  Not brute force any more (the step the reference's
                                   readme.md:38 names, a spatial hierarchy); same bits.  Scenes of fewer
                                   than 97 or more than 4096 traced spheres run RT_KERNEL_STREAM.    */
-    RT_KERNEL_STREAM_MFMA = 5  /* STREAM with the sieve's two dot products (rays x spheres, K = 4) evaluated by the
+    RT_KERNEL_STREAM_MFMA = 5, /* STREAM with the sieve's two dot products (rays x spheres, K = 4) evaluated by the
                                   matrix cores on exact three-term bf16 splits of the f32 operands; the vector
                                   ALU keeps 2 instructions per test.  RT_KERNEL_STREAM picks it by itself from
                                   33 to 1024 traced spheres; this value forces it from 1 sphere on. */
+    RT_KERNEL_LITE = 6,        /* at most 64 traced spheres (else STREAM): one wave per 8x8 tile as in TILE, no work
+                                  queues, with STREAM's sieve and candidate walk and every lane running its
+                                  pixel's frames back to back. */
+    RT_KERNEL_ROWS = 7         /* at most 64 traced spheres (else STREAM): persistent waves whose lanes take work
+                                  path by path, (pixel, frame), and add each pixel's frames in order through
+                                  LDS; RT_KERNEL_STREAM picks it for such scenes. */
 };
 
 /* When the accumulation texel is zeroed. */
@@ -191,14 +197,16 @@ int rt_timer_end(rt_context* ctx, float* ms);
 int rt_dispatch_frames_timed(rt_context* ctx, int n_frames);
 int rt_timed_total(rt_context* ctx, float* ms, int* dispatches);
 
-/* Launch geometry of the stream kernel (0 = choose from the device).  No reference
-   counterpart: the shader's is fixed at local_size 8x8 (res/shaders/shader.comp:2). */
+/* Launch geometry of the stream kernel (0 = choose from the device; threads_per_block a multiple of
+   64 up to 1024, of which the kernel uses at most 512).  No reference counterpart: the shader's is
+   fixed at local_size 8x8 (res/shaders/shader.comp:2). */
 int rt_set_launch(rt_context* ctx, int blocks, int threads_per_block);
 int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* threads);
 /* Where the last stream-kernel dispatch evaluated its sieve: 0 vector ALU with geometry from LDS,
-   1 vector ALU with geometry through the scalar cache, 2 the culled variant, 3 the matrix cores;
-   -1 when the last dispatch ran the tile kernel or nothing has been dispatched.  No reference
-   counterpart. */
+   1 vector ALU with geometry through the scalar cache, 2 the culled variant, 3 the matrix cores,
+   4 the lite kernel (vector ALU, one wave per tile), 5 the rows kernel (vector ALU, work handed out
+   path by path); -1 when the last dispatch ran the tile kernel or nothing has been dispatched.
+   No reference counterpart. */
 int rt_get_sieve_mode(rt_context* ctx, int* mode);
 
 /* Test hook: out[i] = op(a[i], b[i], c[i]) evaluated on the device with the kernels'

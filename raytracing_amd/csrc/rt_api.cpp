@@ -463,12 +463,11 @@ void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const R
     // matrix-core sieve: two waves per SIMD saturate it (measured: 8 waves per CU = 12 = 16); 256-thread
     // workgroups while two of them fit in LDS, else one of 512
     const int t_mfma = rt_stream_lds_bytes(P.n_lds, 256, true) * 2 <= kLdsPerCu ? 256 : 512;
-    int t = want_threads > 0 ? want_threads : (mfma ? t_mfma : P.n_lds <= 1024 ? 256 : 1024);
-    t = std::max(64, std::min(mfma ? RT_MFMA_MAX_THREADS : 1024, t / 64 * 64));
+    int t = want_threads > 0 ? want_threads : (mfma ? t_mfma : P.n_lds <= 1024 ? 256 : RT_STREAM_MAX_THREADS);
+    t = std::max(64, std::min(mfma ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS, t / 64 * 64));
     const size_t lds = rt_stream_lds_bytes(P.n_lds, t, mfma);
     const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
     int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)cu_count ? 8 : 12;
-    if (t == 1024) waves_per_cu = 16;  // whole workgroups: one per CU
     if (mfma) waves_per_cu = 8;
     int per_cu = std::min<int>(std::max(1, waves_per_cu / (t / 64)), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
     per_cu = std::max(1, per_cu);
@@ -542,12 +541,98 @@ void reset_work(rt_context* c)
     if (c->d_work) (void)hipMemsetAsync(c->d_work, 0, RT_WORK_BYTES, c->stream);
 }
 
+// Development knob: what RT_KERNEL_STREAM runs for scenes of at most 64 traced spheres: 2 = the
+// rows kernel, 1 = the lite kernel, 0 = the stream kernel itself, -1 (default) = by dispatch shape.
+int small_scene_kernel()
+{
+    static const int which = [] {
+        const char* e = getenv("RT_DEBUG_LITE");
+        return e ? atoi(e) : -1;
+    }();
+    return which;
+}
+
+int env_int(const char* name, int fallback)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : fallback;
+}
+
+// Launch of rt_rows_kernel: 256-thread workgroups, as many per CU as its LDS holds, and units of
+// PX pixels x all frames with PX the power of two from 8 to 64 that brings a unit closest to a
+// thousand paths (a unit is what a wave cannot share: it bounds how far apart waves finish) and
+// whose rows, 64 / PX frames each, divide the dispatch.
+int launch_rows(rt_context* c, RtParams& P, bool fused)
+{
+    static const int per_cu_env = env_int("RT_DEBUG_ROWS_PER_CU", 0);  // development knobs
+    static const int lpx_env = env_int("RT_DEBUG_ROWS_LPX", 0);
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (int)std::max<size_t>(1, std::min<size_t>(5, kLdsPerCu / rt_rows_lds_bytes(256)));
+    const unsigned ntiles = P.total_pixels / 64u;
+    int blocks = c->blocks > 0 ? c->blocks : c->cu_count * per_cu;
+    blocks = (int)std::max(1u, std::min((unsigned)blocks, (ntiles + 3) / 4));
+    int lpx = 6;
+    while (lpx > 3 && (1 << lpx) * P.n_frames > 1024) lpx--;
+    if (lpx_env >= 3 && lpx_env <= 6) lpx = lpx_env;
+    while (P.n_frames % (64 >> lpx) != 0) lpx++;
+    P.rows_lpx = lpx;
+    // A unit's pixels are PX neighbours of one tile (rows_lgroup = rows_lpx).  Smaller groups
+    // scatter a unit over the image, which evens out the cost of units; measured, that loses more
+    // (neighbouring rays branch alike: walk and shading took twice as long) than it gains.
+    static const int lg_env = env_int("RT_DEBUG_ROWS_LGROUP", -1);
+    P.rows_lgroup = lg_env >= 0 && lg_env <= 6 ? lg_env : lpx;
+    if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
+        return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the rows kernel", P.tile_cols, P.tile_rows);
+    hipError_t e = hipSuccess;
+    if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
+        c->fail_next_launch = false;
+        (void)hipMemsetAsync(c->d_work, 0xff, RT_WORK_BYTES, c->stream);
+        e = hipErrorLaunchFailure;
+    } else {
+        e = rt_launch_rows(P, fused, blocks, c->stream);
+    }
+    if (e != hipSuccess) {
+        reset_work(c);
+        return fail(RT_E_HIP, "rows kernel launch (%d x 256): %s", blocks, hipGetErrorString(e));
+    }
+    c->last_blocks = blocks;
+    c->last_threads = 256;
+    c->last_mode = 5;
+    return RT_OK;
+}
+
 int launch(rt_context* c, const RtParams& P_in, bool record)
 {
     RtParams P = P_in;
     if (P.total_pixels == 0) return RT_OK;
     const bool fused = c->profile == RT_PROFILE_FUSED;
     const bool tile = c->kernel == RT_KERNEL_TILE;
+    // at most 64 traced spheres: the rows kernel (or the lite kernel: one wave per tile with the sieve)
+    const bool small = !record && P.n_pad <= 2 * RT_CHUNK;
+    int which = c->kernel == RT_KERNEL_ROWS ? 2 : c->kernel == RT_KERNEL_LITE ? 1 : 0;
+    if (c->kernel == RT_KERNEL_STREAM) {
+        // The lite kernel unless its units, tile x all frames, are too few and too long for the
+        // hardware dispatcher to balance: many frames of an image of less than about four tiles
+        // per wave slot (measured: 1280x720 x 64 frames 1.45 ms against 1.83 ms; 1920x1080 x 64
+        // frames 3.2 against 3.0 ms).
+        const int env = small_scene_kernel();
+        const unsigned ntiles = P.total_pixels / 64u;
+        which = env >= 0 ? env : (P.n_frames >= 32 && ntiles < 80u * (unsigned)c->cu_count ? 2 : 1);
+    }
+    if (small && which == 2) return launch_rows(c, P, fused);
+    if (small && which == 1) {
+        static const int threads_env = env_int("RT_DEBUG_LITE_THREADS", 0);  // development knob
+        const int threads = threads_env >= 64 && threads_env <= 1024 ? threads_env / 64 * 64 : 256;
+        hipError_t e = hipSuccess;
+        if (c->fail_next_launch) {  // test hook; this kernel keeps no state between launches
+            c->fail_next_launch = false;
+            e = hipErrorLaunchFailure;
+        } else {
+            e = rt_launch_lite(P, fused, threads, c->stream);
+        }
+        if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
+        c->last_mode = 4;
+        return RT_OK;
+    }
     if (tile) {
         HIP_TRY(rt_launch_tile(P, fused, record, c->stream));
         c->last_mode = -1;
@@ -811,7 +896,7 @@ int rt_set_profile(rt_context* c, int profile)
 int rt_set_kernel(rt_context* c, int kernel)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_STREAM_MFMA)
+    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_ROWS)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
@@ -1098,6 +1183,15 @@ int rt_get_counters(rt_context* c, rt_counters* out)
             const unsigned long long* q = slots + i * RT_RAY_SLOT_STRIDE + 8;
             w[0] += q[0]; w[1] += q[1]; w[2] = std::max(w[2], q[2]); w[3] = std::max(w[3], q[3]);
             w[4] = std::max(w[4], q[4]); w[5] += q[5];
+        }
+        if (c->last_mode == 5) {  // rows kernel: words 9, 12, 14, 15 hold its own phases
+            unsigned long long tc = 0, nc = 0, nr = 0, td = 0;
+            for (unsigned i = 0; i < RT_RAY_SLOTS; i++) {
+                const unsigned long long* q = slots + i * RT_RAY_SLOT_STRIDE;
+                tc += q[9]; nc += q[12]; nr += q[14]; td += q[15];
+            }
+            fprintf(stderr, "rows kernel per iteration: summing rows %.0f cycles (%.2f rows), refill steps %.2f, waiting for a run of units %.0f cycles\n",
+                    (double)tc / t[4], (double)nc / t[4], (double)nr / t[4], (double)td / t[4]);
         }
         const double nw = (double)std::max(1ull, w[5]);
         fprintf(stderr, "wave lifetime (us): mean %.1f, shortest %.1f, longest %.1f; after the queues ran dry: mean %.1f, longest %.1f\n",

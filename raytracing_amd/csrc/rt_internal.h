@@ -14,6 +14,9 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
 hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
                                 hipStream_t st);
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
+hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st);
+hipError_t rt_launch_rows(const RtParams& P, bool fused, int blocks, hipStream_t st);
+size_t rt_rows_lds_bytes(int threads);
 hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
                              int y1, float divisor, hipStream_t st);
 hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,

@@ -31,6 +31,12 @@ constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
 // staged in LDS beside the rest.
 constexpr float RT_SIEVE_MARGIN_MFMA = 3.0517578125e-05f;
 constexpr int RT_MAX_MFMA_SPHERES = 1024;
+// Largest workgroup of the stream kernel's vector-ALU instantiations: 8 waves per CU, two per SIMD,
+// which leaves each wave the whole register file (the LDS-geometry sieve wants more than the 128
+// registers of 1024-thread workgroups and spilled to scratch memory under that cap).
+#ifndef RT_STREAM_MAX_THREADS
+#define RT_STREAM_MAX_THREADS 512
+#endif
 // Largest workgroup of the matrix-core instantiation: its operand fragments and accumulators want
 // more registers than 1024-thread workgroups (4 waves per SIMD, 128 registers) leave.
 #ifndef RT_MFMA_MAX_THREADS
@@ -73,6 +79,8 @@ struct RtParams {
     unsigned last_chunk_valid; // bit (31-n) set when sphere n of the last chunk is < sphere_count
     int last_chunk_count;      // spheres in the last chunk (1..32; 0 for an empty scene)
     int prefetch;              // stream kernel: waves ask for their next span one span ahead
+    int rows_lpx;              // rows kernel: log2 of the pixels per unit (3..6)
+    int rows_lgroup;           // rows kernel: log2 of the neighbouring pixels that stay together in a unit (0..3)
     int tile_row0;     // first row of 8x8 tiles rendered
     int tile_rows;     // number of tile rows rendered
     unsigned total_pixels;  // tile_cols * tile_rows * 64

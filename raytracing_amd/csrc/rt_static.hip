@@ -184,12 +184,19 @@ extern "C" int rt_dispatch_static(int device, void* hip_stream, const void* sphe
                                reinterpret_cast<float*>(dev.base + kRadiusAt));
             STATIC_TRY(hipGetLastError());
         }
-        int blocks = 0, threads = 0;
-        rt_stream_geometry(dev.cu_count, 0, 0, P, &blocks, &threads);
-        if (rt_stream_lds_bytes(P.n_lds, threads) > RT_LDS_PER_CU)
-            return rt_fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
-        const int mode = P.n_pad <= RT_MAX_SGPR_SPHERES ? 1 : 0;  // as RT_KERNEL_STREAM chooses
-        STATIC_TRY(rt_launch_stream(P, profile == RT_PROFILE_FUSED, false, mode, blocks, threads, st));
+        // Only kernels that need no scratch memory (private segment) are launched from here: the
+        // runtime allocates that lazily, at the launch of the first kernel that wants more of it.
+        // Those are the lite kernel, up to 64 traced spheres, and the stream kernel with its sieve
+        // geometry in LDS (tests/test_abi.py reads the private segment sizes off the built library).
+        if (P.n_pad <= 2 * RT_CHUNK) {
+            STATIC_TRY(rt_launch_lite(P, profile == RT_PROFILE_FUSED, 256, st));
+        } else {
+            int blocks = 0, threads = 0;
+            rt_stream_geometry(dev.cu_count, 0, 0, P, &blocks, &threads);
+            if (rt_stream_lds_bytes(P.n_lds, threads) > RT_LDS_PER_CU)
+                return rt_fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
+            STATIC_TRY(rt_launch_stream(P, profile == RT_PROFILE_FUSED, false, 0, blocks, threads, st));
+        }
     }
     if (rays_dev) {
         hipLaunchKernelGGL(rt_static_sum_rays_kernel, dim3(1), dim3(64), 0, st, P.rays,

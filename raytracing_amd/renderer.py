@@ -22,6 +22,8 @@ KERNEL_STREAM_SGPR = 2
 KERNEL_STREAM_LDS = 3
 KERNEL_STREAM_CULLED = 4
 KERNEL_STREAM_MFMA = 5
+KERNEL_LITE = 6
+KERNEL_ROWS = 7
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1
 CLEAR_NEVER = 2

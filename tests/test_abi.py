@@ -63,3 +63,26 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 assert "oracle" not in text.lower(), os.path.join(base, f)
+
+
+def test_kernels_of_the_static_entry_point_need_no_scratch_memory():
+    """rt_dispatch_static promises to allocate nothing.  The HIP runtime allocates scratch memory by
+    itself when a kernel with a private segment is first launched, so the kernels that entry point
+    launches -- the lite kernel, the stream kernel with its geometry in LDS (production
+    instantiations), its own two helpers -- must have a private segment of zero bytes and no
+    spilled vector registers.  Read off the code objects embedded in the built library."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+    from raytracing_amd import _native
+
+    res = kernel_resources(_native.LIB_PATH)
+    assert len(res) >= 20
+    wanted = [k for k in res
+              if "rt_lite_kernel" in k or "rt_static_" in k or re.search(r"rt_stream_kernelILb[01]ELb0ELi0E", k)]
+    assert len(wanted) == 6, wanted
+    for k in wanted:
+        assert res[k]["private_segment_fixed_size"] == 0 and res[k]["vgpr_spill_count"] == 0, (k, res[k])
+    # and no production instantiation of any kernel spills vector registers
+    assert all(r["vgpr_spill_count"] == 0 for r in res.values())

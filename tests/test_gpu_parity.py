@@ -17,7 +17,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 PROFILES = [("strict", 0), ("fused", 1)]
-KERNELS = [("stream", 0), ("tile", 1), ("stream_sgpr", 2), ("stream_lds", 3), ("stream_mfma", 5)]
+KERNELS = [("stream", 0), ("tile", 1), ("stream_sgpr", 2), ("stream_lds", 3), ("stream_mfma", 5), ("lite", 6), ("rows", 7)]
 
 
 def _bits(a):
@@ -396,12 +396,15 @@ def test_errors_are_reported(rt, default_scene):
         rt.Renderer(0, 10)
 
 
-def test_failed_launch_is_followed_by_a_correct_one(rt, default_scene):
-    """A stream-kernel launch that fails leaves the work-queue counters as they were (here: as a
-    kernel that died half way would); the dispatch must say so, and the next one must render."""
+@pytest.mark.parametrize("kernel", [0, 2, 5, 6, 7])
+def test_failed_launch_is_followed_by_a_correct_one(rt, default_scene, kernel):
+    """A launch that fails leaves the work-queue counters of the kernels that have them as they were
+    (here: as a kernel that died half way would); the dispatch must say so, and the next one must
+    render."""
     ubo = default_scene.camera.copy()
     ubo["frameCount"][0] = 1
     with rt.Renderer(128, 72) as r:
+        r.set_kernel(kernel)
         r.upload_spheres(default_scene.spheres)
         r.set_uniforms(ubo)
         r.dispatch(1)
