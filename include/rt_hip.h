@@ -65,9 +65,13 @@ enum {
     RT_KERNEL_LITE = 6,        /* at most 64 traced spheres (else STREAM): one wave per 8x8 tile as in TILE, no work
                                   queues, with STREAM's sieve and candidate walk and every lane running its
                                   pixel's frames back to back. */
-    RT_KERNEL_ROWS = 7         /* at most 64 traced spheres (else STREAM): persistent waves whose lanes take work
+    RT_KERNEL_ROWS = 7,        /* at most 64 traced spheres (else STREAM): persistent waves whose lanes take work
                                   path by path, (pixel, frame), and add each pixel's frames in order through
                                   LDS; RT_KERNEL_STREAM picks it for such scenes. */
+    RT_KERNEL_BVH = 8          /* STREAM_CULLED's sorted sphere list walked as a hierarchy by every lane on its
+                                  own: blocks of 64 slots, their groups of 8, the spheres of a group, each level
+                                  behind a bounding sphere (readme.md:38, "BVH implementation"); same bits.
+                                  Same scene sizes as STREAM_CULLED. */
 };
 
 /* When the accumulation texel is zeroed. */
@@ -205,7 +209,7 @@ int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* t
 /* Where the last stream-kernel dispatch evaluated its sieve: 0 vector ALU with geometry from LDS,
    1 vector ALU with geometry through the scalar cache, 2 the culled variant, 3 the matrix cores,
    4 the lite kernel (vector ALU, one wave per tile), 5 the rows kernel (vector ALU, work handed out
-   path by path); -1 when the last dispatch ran the tile kernel or nothing has been dispatched.
+   path by path), 6 the per-lane traversal; -1 when the last dispatch ran the tile kernel or nothing has been dispatched.
    No reference counterpart. */
 int rt_get_sieve_mode(rt_context* ctx, int* mode);
 
@@ -225,12 +229,15 @@ int rt_debug_math(rt_context* ctx, int op, const float* a, const float* b, const
    passed.  No reference counterpart. */
 int rt_debug_sieve_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[4]);
 
-/* Test hook for RT_KERNEL_STREAM_CULLED: runs its group-culling test on n_rays caller-supplied
-   rays against the bounding spheres of the sorted sphere groups.  out[0]: (ray, sphere) pairs
-   whose group was culled although the sphere's literal discriminant (either float profile) was
-   not negative -- must be 0; out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs
-   tested.  No reference counterpart. */
-int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[3]);
+/* Test hook for RT_KERNEL_STREAM_CULLED and RT_KERNEL_BVH: runs their culling test on n_rays
+   caller-supplied rays against the bounding spheres of the sorted list's groups of 8 slots and
+   blocks of 64.  out[0]: (ray, sphere) pairs whose group or block was culled although the sphere's
+   literal discriminant (either float profile) was not negative -- must be 0; out[1]: (ray, group)
+   pairs culled; out[2]: (ray, group) pairs tested; out[3], out[4]: the same for blocks; out[5]:
+   literal hits that RT_KERNEL_BVH's distance test would prune (the sphere itself, its group or its
+   block) when the nearest hit so far is that very hit -- must be 0; out[6]: literal hits so
+   examined.  No reference counterpart. */
+int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[7]);
 
 /* Test hook: the next stream-kernel launch of this context is not made; that dispatch returns
    RT_E_HIP and leaves the work-queue counters as a kernel that died half way would.  The

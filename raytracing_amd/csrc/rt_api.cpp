@@ -90,7 +90,7 @@ struct rt_context {
     int cull_count = -1;          // sphere_count the sorted copy was built for; -1 = none / stale
 
     int last_blocks = 0, last_threads = 0; // geometry of the last stream-kernel launch
-    int last_mode = -1;                    // and its sieve: 0 LDS, 1 scalar cache, 2 culled, 3 matrix cores; -1 none yet / tile kernel
+    int last_mode = -1;                    // and its sieve: the values of rt_get_sieve_mode
     unsigned* d_work = nullptr;           // RT_WORK_BYTES: span counters + finished-workgroup count
     unsigned long long* d_rays = nullptr; // RT_RAY_BYTES: ray counters, summed by rt_get_counters
     uint64_t paths = 0;
@@ -325,7 +325,7 @@ uint32_t morton10(uint32_t v)  // spread the low 10 bits of v three apart
 struct CulledScene {
     std::vector<float> geom;    // 4 floats per slot, pair-packed
     std::vector<float> radius;  // per slot
-    std::vector<float> bounds;  // 4 floats per group, pair-packed, padded to 64 groups
+    std::vector<float> bounds;  // 4 floats per group, pair-packed, padded to 64 groups; then RT_BVH_BLOCKS block bounds
     std::vector<int> perm;      // per slot
 };
 
@@ -379,7 +379,7 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
     out->geom.assign((size_t)n_pad * 4, 0.f);
     out->radius.assign((size_t)n_pad, 0.f);
     out->perm.assign((size_t)n_pad, 0);
-    out->bounds.assign((size_t)nbounds * 4, 0.f);
+    out->bounds.assign((size_t)(nbounds + RT_BVH_BLOCKS) * 4, 0.f);
     auto put = [](std::vector<float>& v, int slot, float x, float y, float z, float w) {
         const size_t base = (size_t)(slot >> 1) * 8 + (slot & 1);
         v[base + 0] = x; v[base + 2] = y; v[base + 4] = z; v[base + 6] = w;
@@ -394,8 +394,12 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
             put(out->geom, k, 0.f, 0.f, 0.f, -inf);  // padding: rejected whatever the ray
         }
     }
-    for (int g = 0; g < nbounds; g++) {
-        const int first = g * RT_CULL_GROUP, end = std::min(count, first + RT_CULL_GROUP);
+    // entries 0 .. nbounds-1: the groups of RT_CULL_GROUP slots; entries nbounds .. : the blocks of
+    // RT_BVH_BLOCK slots (per-lane traversal), by the same construction over all their members
+    for (int g = 0; g < nbounds + RT_BVH_BLOCKS; g++) {
+        const bool block = g >= nbounds;
+        const int first = block ? (g - nbounds) * RT_BVH_BLOCK : g * RT_CULL_GROUP;
+        const int end = std::min(count, first + (block ? RT_BVH_BLOCK : RT_CULL_GROUP));
         if (first >= count) {
             put(out->bounds, g, 0.f, 0.f, 0.f, -inf);  // no spheres: never needed
             continue;
@@ -502,7 +506,7 @@ int ensure_culled(rt_context* c, int count, int n_pad)
         const size_t nbounds = ((size_t)n_pad / RT_CULL_GROUP + 63) / 64 * 64;
         HIP_TRY(hipMalloc(&c->d_cgeom, (size_t)n_pad * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->d_cradius, (size_t)n_pad * sizeof(float)));
-        HIP_TRY(hipMalloc(&c->d_bounds, nbounds * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_bounds, (nbounds + RT_BVH_BLOCKS) * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->d_perm, (size_t)n_pad * sizeof(int)));
         c->cull_cap = n_pad;
     }
@@ -528,6 +532,7 @@ int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false)
     P->geom = c->d_cgeom;
     P->radius = c->d_cradius;
     P->bounds = c->d_bounds;
+    P->n_bounds = (P->n_pad / RT_CULL_GROUP + 63) / 64 * 64;
     P->perm = c->d_perm;
     *on = true;
     return RT_OK;
@@ -651,15 +656,17 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     // workgroup zeroes it again on its way out, so no launch needs a memset in front of it; a
     // launch or a synchronisation that fails zeroes it here (reset_work).
     // The scalar cache serves the sieve faster than LDS while the geometry stream fits in it.
-    int mode = c->kernel == RT_KERNEL_STREAM_SGPR || c->kernel == RT_KERNEL_STREAM_CULLED ||
+    int mode = c->kernel == RT_KERNEL_STREAM_SGPR || c->kernel == RT_KERNEL_STREAM_CULLED || c->kernel == RT_KERNEL_BVH ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES)
                    ? 1 : 0;
     if (mfma) mode = 3;
-    if (c->kernel == RT_KERNEL_STREAM_CULLED) {
+    if (c->kernel == RT_KERNEL_STREAM_CULLED || c->kernel == RT_KERNEL_BVH) {
         bool on = false;
         const int rc = use_culled(c, &P, &on);
         if (rc != RT_OK) return rc;
-        if (on) mode = 2;
+        if (on) mode = c->kernel == RT_KERNEL_BVH && P.n_pad <= RT_BVH_BLOCK * RT_BVH_BLOCKS ? 4 : 2;
+        if (mode == 4 && rt_stream_lds_bytes(P.n_lds, threads, false, P.n_bounds) > kLdsPerCu)
+            return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     }
     hipError_t e = hipSuccess;
     if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
@@ -675,7 +682,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     }
     c->last_blocks = blocks;
     c->last_threads = threads;
-    c->last_mode = mode;
+    c->last_mode = mode == 4 ? 6 : mode;
     return RT_OK;
 }
 
@@ -896,7 +903,7 @@ int rt_set_profile(rt_context* c, int profile)
 int rt_set_kernel(rt_context* c, int kernel)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_ROWS)
+    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_BVH)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
@@ -1169,6 +1176,11 @@ int rt_get_counters(rt_context* c, rt_counters* out)
     unsigned long long passes = 0;
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passes += slots[i * RT_RAY_SLOT_STRIDE + 1];
     fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)rays / passes : 0.0);
+    unsigned long long bvh[2];
+    rt_bvh_step_counts(bvh);
+    if (bvh[0])
+        fprintf(stderr, "per-lane traversal: %.2f steps per pass, %.2f of 64 lanes at work in a step\n",
+                (double)bvh[0] / passes, (double)bvh[1] / bvh[0]);
 #endif
 #ifdef RT_PHASE_TIMERS
     {
@@ -1292,7 +1304,7 @@ int rt_debug_sieve_audit(rt_context* c, const float* rays, int n_rays, uint64_t 
 }
 
 // Audit of the culled kernel's group test (see rt_cull_audit_kernel).
-int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t out[3])
+int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t out[7])
 {
     if (!c || !rays || !out || n_rays <= 0) return fail(RT_E_INVALID, "bad argument");
     RT_ON_DEVICE(c);
@@ -1306,17 +1318,17 @@ int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t o
     float* d_rays = nullptr;
     unsigned long long* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 6 * sizeof(float)));
-    hipError_t e = hipMalloc(&d_out, 3 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), c->stream);
+    hipError_t e = hipMalloc(&d_out, 7 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 7 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n_rays * 6 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = rt_launch_cull_audit(P, d_rays, n_rays, d_out, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    unsigned long long host[3] = {0, 0, 0};
+    unsigned long long host[7] = {0, 0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(host, d_out, sizeof host, hipMemcpyDeviceToHost);
     (void)hipFree(d_rays);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(RT_E_HIP, "cull audit: %s", hipGetErrorString(e));
-    for (int i = 0; i < 3; i++) out[i] = host[i];
+    for (int i = 0; i < 7; i++) out[i] = host[i];
     return RT_OK;
 }
 

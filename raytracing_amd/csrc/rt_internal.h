@@ -8,7 +8,7 @@
 #include "rt_params.h"
 
 // ---- rt_kernels.hip
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma = false);
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma = false, int n_bounds = 0);
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st);
 hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
@@ -17,6 +17,9 @@ hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_
 hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st);
 hipError_t rt_launch_rows(const RtParams& P, bool fused, int blocks, hipStream_t st);
 size_t rt_rows_lds_bytes(int threads);
+#ifdef RT_COUNT_PASSES
+void rt_bvh_step_counts(unsigned long long out[2]);  // experiment build: traversal steps since the last call
+#endif
 hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
                              int y1, float divisor, hipStream_t st);
 hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,

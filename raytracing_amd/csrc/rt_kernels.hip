@@ -1340,22 +1340,181 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
     return summary << (32 - nsg);
 }
 
-// Persistent kernel.  blockDim.x is a multiple of 64 (<= 1024); dynamic LDS =
-// n_pad*16 B sieve geometry + n_pad*4 B radii + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
+// ------------------------------------------------- per-lane traversal (MODE 4)
+//
+// Trace() over the spatially sorted sphere list as a walk down an implicit 8-ary hierarchy, every
+// lane on its own: blocks of RT_BVH_BLOCK = 64 slots, their 8 groups of RT_CULL_GROUP = 8 slots,
+// the 8 spheres of a group.  Blocks and groups carry the bounding spheres build_culled() makes
+// (conservative against every member's own sieve), tested with the sieve itself:
+//   - top: the block bounds (at most 64) are sieved by the whole wave from the scalar cache, one
+//     64-bit mask of blocks per lane;
+//   - then a lane takes its work one NODE at a time -- the next group of its open block, else the
+//     next block of its mask -- reads the node's 8 entries (group bounds, or spheres) from LDS at
+//     its own address (8 x ds_read_b128), and sieves them; the entries of a block that pass open
+//     its groups, the spheres of a group that pass get the shader's literal test at once.  Lanes
+//     on a block and lanes on a group run the same instructions; only the margin constant differs.
+// What the wave-level OR of the culled kernel gives away to incoherent rays stays here: a lane
+// visits only what its own ray may touch, and of that only what lies in front of its origin and
+// not beyond the nearest hit it has found so far (bvh_pair).  Ties go to the lowest ORIGINAL index (test_sphere with
+// the slot -> index table), whatever the order of the visits.
+// The verdict on one pair of entries (spheres, or bounding spheres) for one ray: the sign bit of the
+// sieve's g as in sieve_pair, OR two tests on the same intermediate values that the brute-force
+// kernels have no use for.  With s = n.(o - c) and t = r^2 - |o - c|^2 + m (n = d/|d|, m the margin),
+// g = s^2 + t, and bh = (best t so far) * |d|:
+//   - behind:  s > 0 and t < 0 -- the origin lies outside the sphere (inflated by m) and the centre
+//     behind it: both roots are negative;
+//   - beyond:  s + bh < 0 and bh (bh + 2 s) - t > 0 -- the ray enters the inflated sphere only after
+//     bh: nothing in it can be as near as the hit already found (a tie included).
+// Why that is safe: the shader's own t of a sphere, times |d|, is never below the exact entry
+// distance into that sphere inflated by E = 21u|o-c|^2 + 7u r^2 (u = 2^-24; the error bound of its
+// discriminant), less a few u of |o - c|; the sieve inflates by m = 256u (o.o + c.c + r.r) >= 6 E, and
+// all rounding in s, t, bh and the expression above stays below 111u (o.o + c.c + r.r) of the 213u
+// that difference leaves.  A bounding sphere of build_culled(), inflated by its own margin
+// (2^-9 o.o on the ray's side), contains every member inflated by m, so what holds for its
+// entry distance holds for its members'.  bh = +inf (no hit yet) prunes nothing.
+__device__ __forceinline__ void bvh_pair(uint32_t& mask, v4f A, v4f B, const SieveRay& r, v2f bh)
+{
+    const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, w = {B.z, B.w};
+    const v2f s = __builtin_elementwise_fma(
+        cz, r.nnz, __builtin_elementwise_fma(cy, r.nny, __builtin_elementwise_fma(cx, r.nnx, r.d0)));
+    const v2f t = __builtin_elementwise_fma(
+        cz, r.p2oz, __builtin_elementwise_fma(cy, r.p2oy, __builtin_elementwise_fma(cx, r.p2ox, r.no2 + w)));
+    const v2f q = __builtin_elementwise_fma(s, s, t);
+    const v2f h = s + bh;
+    const v2f f = __builtin_elementwise_fma(bh, s + h, -t);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t sb = __float_as_uint(s[k]), tb = __float_as_uint(t[k]), qb = __float_as_uint(q[k]);
+        const uint32_t hb = __float_as_uint(h[k]), fb = __float_as_uint(f[k]);
+        const uint32_t verdict = qb | (~sb & tb) | (~fb & hb);  // sign bit set: rejected
+        mask = __builtin_amdgcn_alignbit(mask, verdict, 31);
+    }
+}
+
+// bh of bvh_pair for a ray: best * |d|, with |d| = a * rsq(a) as the sieve's normalisation has it.
+__device__ __forceinline__ float bvh_reach(float best, float a)
+{
+    return best * (a * __builtin_amdgcn_rsqf(a));
+}
+
+#ifdef RT_COUNT_PASSES
+static __device__ unsigned long long g_bvh_count[2];  // experiment: wave-level steps, lane-level steps
+#define g_bvh_steps bvh_steps_
+#endif
+
+template <bool FUSED>
+__device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, const RtParams& P, const float4* lds_geom,
+                                          const float* lds_radius, int bounds_at, float& best, int& idx)
+{
+#ifdef RT_COUNT_PASSES
+    unsigned bvh_steps_ = 0;
+#endif
+    const SieveRay sr = sieve_ray(p, a, alive);
+    const SieveRay srb = sieve_ray(p, a, alive, RT_CULL_MARGIN_O);
+    // block bounds: entries P.n_bounds .. of P.bounds, 4 at a time from the scalar cache
+    const int nblk = (P.n_pad + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK;
+    const int n4 = (nblk + 3) >> 2;
+    ConstGeomPtr bb = (ConstGeomPtr)(const void*)(P.bounds) + P.n_bounds;
+    const v2f none = {__builtin_inff(), __builtin_inff()};
+    uint32_t rej0 = 0u, rej1 = 0u;
+#pragma unroll 1
+    for (int n = 0; n < min(n4, 8); n++) {
+        bvh_pair(rej0, bb[4 * n], bb[4 * n + 1], srb, none);
+        bvh_pair(rej0, bb[4 * n + 2], bb[4 * n + 3], srb, none);
+    }
+#pragma unroll 1
+    for (int n = 8; n < n4; n++) {
+        bvh_pair(rej1, bb[4 * n], bb[4 * n + 1], srb, none);
+        bvh_pair(rej1, bb[4 * n + 2], bb[4 * n + 3], srb, none);
+    }
+    // bit (31 - n): block n (bm0) / block 32 + n (bm1) may be touched; what was not evaluated has no spheres
+    uint32_t bm0 = n4 > 0 ? ~rej0 << (32 - 4 * min(n4, 8)) : 0u;
+    uint32_t bm1 = n4 > 8 ? ~rej1 << (32 - 4 * (n4 - 8)) : 0u;
+    uint32_t gm = 0;  // bit (31 - k): group k of the open block is still to be visited
+    int blk = 0;
+    const v4f* base = reinterpret_cast<const v4f*>(lds_geom);
+    const float* gf = reinterpret_cast<const float*>(lds_geom);
+    for (;;) {
+        const bool leaf = gm != 0u;
+        const bool inner = !leaf && (bm0 | bm1) != 0u;
+        if (__ballot(leaf || inner) == 0ull) break;
+#ifdef RT_COUNT_PASSES
+        g_bvh_steps += (leaf || inner) ? 0x10001u : 0x10000u;  // experiment: wave steps << 16 | this lane's steps
+#endif
+        int node = 0;  // float4 index of the node's 8 entries
+        int grp = 0;
+        if (leaf) {
+            const int k = __clz(gm);
+            gm &= ~(0x80000000u >> k);
+            grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + k;
+            node = grp * RT_CULL_GROUP;
+        } else if (inner) {
+            if (bm0 != 0u) {
+                blk = __clz(bm0);
+                bm0 &= ~(0x80000000u >> blk);
+            } else {
+                const int k = __clz(bm1);
+                bm1 &= ~(0x80000000u >> k);
+                blk = 32 + k;
+            }
+            node = bounds_at + blk * (RT_BVH_BLOCK / RT_CULL_GROUP);
+        }
+        const v4f* g = base + node;
+        v4f e[RT_CULL_GROUP];
+#pragma unroll
+        for (int k = 0; k < RT_CULL_GROUP; k++) e[k] = g[k];
+        SieveRay s2 = sr;
+        s2.no2 = leaf ? sr.no2 : srb.no2;
+        const float reach = bvh_reach(best, a);
+        const v2f bh = {reach, reach};
+        uint32_t rej = 0;
+#pragma unroll
+        for (int k = 0; k < RT_CULL_GROUP / 2; k++) bvh_pair(rej, e[2 * k], e[2 * k + 1], s2, bh);
+        const uint32_t pass = (~rej) << (32 - RT_CULL_GROUP);  // bit (31 - k): entry k passed
+        if (inner) gm = pass;
+        uint32_t cand = leaf ? pass : 0u;
+        while (__ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int b = __clz(cand);
+                cand &= ~(0x80000000u >> b);
+                const int i = grp * RT_CULL_GROUP + b;
+                bool far_root = false;
+                if (P.materials != nullptr) far_root = P.materials[P.perm[i]].x == 3.0f;  // wave-uniform branch
+                const float* f = gf + (i >> 1) * 8 + (i & 1);
+                test_sphere<FUSED>(p, a, f[0], f[2], f[4], lds_radius[i], i, best, idx, far_root, P.perm);
+            }
+        }
+    }
+#ifdef RT_COUNT_PASSES
+    unsigned long long lanes = bvh_steps_ & 0xffffu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lanes += __shfl_down(lanes, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_bvh_count[0], (unsigned long long)(bvh_steps_ >> 16));
+        atomicAdd(&g_bvh_count[1], lanes);
+    }
+#endif
+}
+
+// Persistent kernel.  blockDim.x is a multiple of 64 (<= RT_STREAM_MAX_THREADS); dynamic LDS =
+// rt_stream_lds_bytes(): n_pad*16 B sieve geometry + n_pad*4 B radii + per mode the matrix-core
+// operands or the group bounds + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
 //
 // MODE selects where the sieve reads the geometry from: 0 = the LDS copy (wave-uniform
 // ds_read_b128), 1 = global memory through the scalar cache (s_load into SGPRs, which the
 // packed instructions take directly as their one scalar operand).  The walk reads LDS either way.
 // 2 = as 1, over the spatially sorted sphere list with group culling: per 512 spheres the wave
 // first sieves the 64 bounding spheres of their groups of 8, ORs the result over its lanes, and
-// skips the groups no lane can touch.
-
+// skips the groups no lane can touch.  3 = the sieve on the matrix cores.  4 = per-lane traversal
+// of the sorted list (trace_bvh).
 template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
 {
     constexpr bool SGEOM = MODE == 1 || MODE == 2;
     constexpr bool CULL = MODE == 2;
     constexpr bool MFMA = MODE == 3;
+    constexpr bool BVH = MODE == 4;
+    constexpr bool SORTED = CULL || BVH;  // slots of the sorted list: P.perm maps them to the shader's indices
     extern __shared__ float4 smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1369,8 +1528,10 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     }
     // matrix-core sieve: the sphere-side operand fragments follow (128 x 16 bytes per chunk)
     uint4* frags = reinterpret_cast<uint4*>(radius + P.n_lds);
-    const int n_frag = MFMA ? P.n_lds * 4 : 0;
-    for (int i = threadIdx.x; i < n_frag; i += blockDim.x) frags[i] = P.frags[i];
+    // matrix-core sieve: the sphere-side operands; per-lane traversal: the bounding spheres of the groups
+    const int n_frag = MFMA ? P.n_lds * 4 : BVH ? P.n_bounds : 0;
+    for (int i = threadIdx.x; i < n_frag; i += blockDim.x)
+        frags[i] = BVH ? reinterpret_cast<const uint4*>(P.bounds)[i] : P.frags[i];
     __syncthreads();  // the only barrier: waves run independently from here on
     uint32_t* wmask = reinterpret_cast<uint32_t*>(frags + n_frag) + wave * (RT_SG_CHUNKS * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
@@ -1512,7 +1673,10 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
         int idx = -1;
-        {
+        if constexpr (BVH) {
+            trace_bvh<FUSED>(p, a, alive, P, smem, radius, (int)(reinterpret_cast<const float4*>(frags) - smem), best, idx);
+            RT_MARK(t_walk)
+        } else {
             SieveRay sr;
             MfmaRay mr;
             if constexpr (MFMA)
@@ -1615,7 +1779,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             }
         }
 
-        if constexpr (CULL)
+        if constexpr (SORTED)
             if (idx >= 0) idx = P.perm[idx];  // slot of the sorted list -> the shader's sphere index
 
         // ---- shade
@@ -1742,7 +1906,11 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
 // the kernel does (per lane, before the OR over the wave) and, for every group it would cull,
 // the literal discriminant of the group's spheres under both float profiles.
 // out[0]: (ray, sphere) pairs culled with a non-negative discriminant (must stay 0);
-// out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs tested.  blockDim.x = 256.
+// out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs tested; out[3], out[4]: the same
+// for the blocks of RT_BVH_BLOCK slots the per-lane traversal tests first (with its "behind" test);
+// out[5]: spheres with a literal hit that the traversal's distance test would prune, itself or by
+// its group or block, when the nearest hit so far is that very hit (must stay 0); out[6]: literal
+// hits so examined.  blockDim.x = 256.
 __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, const float* rays, int n_rays,
                                                            unsigned long long* out)
 {
@@ -1777,9 +1945,77 @@ __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, co
             }
         }
     }
+    // the blocks of RT_BVH_BLOCK slots (per-lane traversal), evaluated as trace_bvh does
+    unsigned bculled = 0, btested = 0;
+    const int nblk = (P.n_pad + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK;
+    for (int b0 = 0; b0 < nblk; b0 += RT_CHUNK) {
+        const int n4 = min(8, (nblk - b0 + 3) >> 2);
+        uint32_t rej = 0;
+        const v2f none = {__builtin_inff(), __builtin_inff()};
+        const v4f* bb = reinterpret_cast<const v4f*>(P.bounds) + P.n_bounds + b0;
+        for (int n = 0; n < n4; n++) {
+            bvh_pair(rej, bb[4 * n], bb[4 * n + 1], srb, none);
+            bvh_pair(rej, bb[4 * n + 2], bb[4 * n + 3], srb, none);
+        }
+        rej <<= 32 - 4 * n4;
+        for (int n = 0; n < RT_CHUNK && b0 + n < nblk && live; n++) {
+            const int first = (b0 + n) * RT_BVH_BLOCK;
+            if (first >= P.sphere_count) break;
+            btested++;
+            if (!((rej >> (31 - n)) & 1u)) continue;
+            bculled++;
+            // a block is also dropped when it lies behind the origin: what counts here is a hit
+            // (either root positive: the far one is what a dielectric sphere may take)
+            for (int k = first; k < first + RT_BVH_BLOCK && k < P.sphere_count; k++) {
+                const float4 g = *reinterpret_cast<const float4*>(P.spheres + P.perm[k]);
+                float ts = RT_FLT_MAX, tf = RT_FLT_MAX;
+                int is = -1, jf = -1;
+                test_sphere<false>(p, a_s, g.x, g.y, g.z, g.w, k, ts, is, true);
+                test_sphere<true>(p, a_f, g.x, g.y, g.z, g.w, k, tf, jf, true);
+                if (is >= 0 || jf >= 0) bad++;
+            }
+        }
+    }
+    // The distance test of the per-lane traversal (bvh_pair): with "best" set to a sphere's own
+    // literal t, neither the sphere nor its group nor its block may be rejected -- the sharpest case
+    // of "nothing as near as the hit found so far is pruned", a tie.  Both float profiles.
+    unsigned pruned = 0, hits = 0;
+    const SieveRay sr_s = sieve_ray(p, a_s, true), sr_f = sieve_ray(p, a_f, true);
+    const SieveRay srb_f = sieve_ray(p, a_f, true, RT_CULL_MARGIN_O);
+    const v4f* geom = reinterpret_cast<const v4f*>(P.geom);
+    const v4f* bnd = reinterpret_cast<const v4f*>(P.bounds);
+    for (int k = 0; k < P.sphere_count && live; k++) {
+        const float4 g = *reinterpret_cast<const float4*>(P.spheres + P.perm[k]);
+        float ts = RT_FLT_MAX, tf = RT_FLT_MAX;
+        int is = -1, jf = -1;
+        const bool far = (k & 1) != 0;  // every other sphere as a dielectric one would be tested
+        test_sphere<false>(p, a_s, g.x, g.y, g.z, g.w, k, ts, is, far);
+        test_sphere<true>(p, a_f, g.x, g.y, g.z, g.w, k, tf, jf, far);
+        for (int prof = 0; prof < 2; prof++) {
+            if ((prof ? jf : is) < 0) continue;
+            hits++;
+            const float reach = bvh_reach(prof ? tf : ts, prof ? a_f : a_s);
+            const v2f bh = {reach, reach};
+            uint32_t m = 0;
+            bvh_pair(m, geom[(k >> 1) * 2], geom[(k >> 1) * 2 + 1], prof ? sr_f : sr_s, bh);
+            bool rejected = ((m >> (1 - (k & 1))) & 1u) != 0u;
+            const int grp = k / RT_CULL_GROUP, blk = k / RT_BVH_BLOCK + P.n_bounds;
+            m = 0;
+            bvh_pair(m, bnd[(grp >> 1) * 2], bnd[(grp >> 1) * 2 + 1], prof ? srb_f : srb, bh);
+            rejected = rejected || ((m >> (1 - (grp & 1))) & 1u) != 0u;
+            m = 0;
+            bvh_pair(m, bnd[(blk >> 1) * 2], bnd[(blk >> 1) * 2 + 1], prof ? srb_f : srb, bh);
+            rejected = rejected || ((m >> (1 - (blk & 1))) & 1u) != 0u;
+            if (rejected) pruned++;
+        }
+    }
+    if (pruned) atomicAdd(out + 5, (unsigned long long)pruned);
+    if (hits) atomicAdd(out + 6, (unsigned long long)hits);
     if (bad) atomicAdd(out + 0, (unsigned long long)bad);
     if (culled) atomicAdd(out + 1, (unsigned long long)culled);
     if (tested) atomicAdd(out + 2, (unsigned long long)tested);
+    if (bculled) atomicAdd(out + 3, (unsigned long long)bculled);
+    if (btested) atomicAdd(out + 4, (unsigned long long)btested);
 }
 
 // ------------------------------------------------------------------- resolve
@@ -1838,20 +2074,21 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma)
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int n_bounds)
 {
     return (size_t)n_lds * (sizeof(float4) + sizeof(float) + (mfma ? 4 * sizeof(uint4) : 0)) +
-           (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
+           (size_t)n_bounds * sizeof(float4) + (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
 }
 
 // mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
-// 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0)
+// 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0), 4 = per-lane traversal (P.bounds/P.perm/P.n_bounds
+// set, P.n_lds != 0)
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
     if (threads < 64 || threads % 64 != 0 || threads > (mode == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS))
         return hipErrorInvalidConfiguration;  // beyond the instantiation's launch bounds
-    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3);
+    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds : 0);
     static const size_t pad = [] {
         const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
         return e ? (size_t)atol(e) : (size_t)0;
@@ -1863,6 +2100,13 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
                          : launch_stream<false, true, 2>(P, blocks, threads, lds, st);
         return fused ? launch_stream<true, false, 2>(P, blocks, threads, lds, st)
                      : launch_stream<false, false, 2>(P, blocks, threads, lds, st);
+    }
+    if (mode == 4) {
+        if (record)
+            return fused ? launch_stream<true, true, 4>(P, blocks, threads, lds, st)
+                         : launch_stream<false, true, 4>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, false, 4>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 4>(P, blocks, threads, lds, st);
     }
     if (mode == 3) {
         if (record)
@@ -1891,6 +2135,15 @@ hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays
     hipLaunchKernelGGL(rt_cull_audit_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, st, P, rays, n_rays, out);
     return hipGetLastError();
 }
+
+#ifdef RT_COUNT_PASSES
+void rt_bvh_step_counts(unsigned long long out[2])
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_count), 16);
+    const unsigned long long zero[2] = {0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_count), zero, 16);
+}
+#endif
 
 size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4); }
 

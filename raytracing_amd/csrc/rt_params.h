@@ -46,6 +46,10 @@ constexpr int RT_MAX_MFMA_SPHERES = 1024;
 // (2^-9; see build_culled in rt_api.cpp for why it is larger than the sieve's).
 constexpr int RT_CULL_GROUP = 8;
 constexpr float RT_CULL_MARGIN_O = 0.001953125f;
+// Per-lane traversal (RT_KERNEL_BVH): slots per block (8 groups), and the number of block entries
+// that follow the group bounds (RT_MAX_LDS_SPHERES / RT_BVH_BLOCK, two chunks of the sieve).
+constexpr int RT_BVH_BLOCK = 64;
+constexpr int RT_BVH_BLOCKS = 64;
 // Pixels a wave takes from a work queue at a time (one 8x8 tile).
 #ifndef RT_SPAN_PIXELS
 #define RT_SPAN_PIXELS 64
@@ -100,6 +104,8 @@ struct RtParams {
     // culled kernel only: geom/radius above are the spatially sorted copies, and
     const float4* bounds;        // pair-packed like geom: bounding sphere of every group of 8 slots,
                                  // padded to a multiple of 64 groups with never-touched entries
+                                 // and after those the RT_BVH_BLOCKS bounding spheres of the blocks of 64 slots
+    int n_bounds;                // group entries in `bounds` (a multiple of 64)
     const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8

@@ -24,6 +24,7 @@ KERNEL_STREAM_CULLED = 4
 KERNEL_STREAM_MFMA = 5
 KERNEL_LITE = 6
 KERNEL_ROWS = 7
+KERNEL_BVH = 8
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1
 CLEAR_NEVER = 2
@@ -207,9 +208,11 @@ class Renderer:
     def cull_audit(self, rays: np.ndarray) -> dict:
         """rays: (n, 6) float32 origin+direction; see rt_debug_cull_audit in include/rt_hip.h."""
         arr = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
-        out = (C.c_uint64 * 3)()
+        out = (C.c_uint64 * 7)()
         N.check(N.lib().rt_debug_cull_audit(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0], out))
-        return {"missed": int(out[0]), "culled": int(out[1]), "tested": int(out[2])}
+        return {"missed": int(out[0]), "culled": int(out[1]), "tested": int(out[2]),
+                "blocks_culled": int(out[3]), "blocks_tested": int(out[4]),
+                "hits_pruned": int(out[5]), "hits": int(out[6])}
 
     def debug_math(self, op: int, a, b=None, c=None) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)

@@ -1,7 +1,9 @@
-"""GPU parity of RT_KERNEL_STREAM_CULLED: the stream kernel over a spatially sorted copy of the
-sphere list that skips groups of 8 spheres no ray of a wave can touch.  It is not brute force any
-more, so it is not what the headline benchmark runs; its results must still be the oracle's bit
-for bit -- same hit indices (ties go to the lowest ORIGINAL index), same images, same ray count."""
+"""GPU parity of RT_KERNEL_STREAM_CULLED, the stream kernel over a spatially sorted copy of the
+sphere list that skips groups of 8 spheres no ray of a wave can touch, and of RT_KERNEL_BVH, which
+walks the same list as a hierarchy (blocks of 64, groups of 8, spheres) lane by lane.  Neither is
+brute force any more, so neither is what the headline benchmark runs; their results must still be
+the oracle's bit for bit -- same hit indices (ties go to the lowest ORIGINAL index), same images,
+same ray count."""
 import numpy as np
 import pytest
 
@@ -11,6 +13,8 @@ from test_gpu_parity import _bits, _render_cpu, _render_gpu, _tangent_rays
 pytestmark = pytest.mark.gpu
 
 CULLED = 4
+BVH = 8
+BOTH = pytest.mark.parametrize("kernel", [CULLED, BVH], ids=["culled", "bvh"])
 
 
 @pytest.fixture(scope="module")
@@ -49,38 +53,44 @@ def test_group_test_never_culls_a_literal_candidate(rt, default_scene, rtiow_sce
         res = r.cull_audit(rays)
     assert res["missed"] == 0, res
     assert res["tested"] > 0 and res["culled"] > 0.1 * res["tested"], res
+    assert res["hits"] > 1000 and res["hits_pruned"] == 0, res
+    assert res["blocks_tested"] > 0 and (len(sph) < 128 or res["blocks_culled"] > 0.02 * res["blocks_tested"]), res
 
 
+@BOTH
 @pytest.mark.parametrize("profile", [0, 1])
-def test_culled_images_match_oracle(rt, default_scene, rtiow_scene, profile):
+def test_culled_images_match_oracle(rt, default_scene, rtiow_scene, profile, kernel):
     for scene, (w, h), frames, depth in ((default_scene, (320, 184), 3, 50), (rtiow_scene, (320, 184), 4, 50)):
-        acc, col, cnt = _render_gpu(rt, scene, w, h, profile=profile, kernel=CULLED, n_frames=frames, depth=depth)
+        acc, col, cnt = _render_gpu(rt, scene, w, h, profile=profile, kernel=kernel, n_frames=frames, depth=depth)
         cacc, ccol, crays = _render_cpu(scene, w, h, profile=profile, n_frames=frames, depth=depth)
         assert np.array_equal(_bits(acc), _bits(cacc))
         assert np.array_equal(col, ccol)
         assert cnt["rays"] == crays
 
 
+@BOTH
 @pytest.mark.parametrize("count", [0, 1, 33, 96, 97, 100, 121, 128, 129, 255, 481, 513, 1025, 4096])
-def test_culled_sphere_counts(rt, count):
+def test_culled_sphere_counts(rt, count, kernel):
     """Ragged groups and chunks, the 512-sphere supergroup boundary, the smallest (97) and largest
     (4096) scenes the culled kernel takes (smaller ones run the brute-force kernel);
     sphere_count smaller than the upload (the sorted copy holds the traced ones only)."""
     scene = rt.Scene.generate(rt.KIND_CUBE, max(count, 3) + 5, 11)
-    acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=0, kernel=CULLED, n_frames=2, depth=6, sphere_count=count)
+    acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=0, kernel=kernel, n_frames=2, depth=6, sphere_count=count)
     cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=0, n_frames=2, depth=6, sphere_count=count)
     assert np.array_equal(_bits(acc), _bits(cacc)), count
     assert np.array_equal(col, ccol) and cnt["rays"] == crays
 
 
-def test_culled_falls_back_above_4096_spheres(rt):
+@BOTH
+def test_culled_falls_back_above_4096_spheres(rt, kernel):
     scene = rt.Scene.generate(rt.KIND_CUBE, 5000, 21)
-    acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=1, kernel=CULLED, n_frames=1, depth=4)
+    acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=1, kernel=kernel, n_frames=1, depth=4)
     cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=1, n_frames=1, depth=4)
     assert np.array_equal(_bits(acc), _bits(cacc)) and cnt["rays"] == crays
 
 
-def test_culled_ties_degenerates_and_records(rt):
+@BOTH
+def test_culled_ties_degenerates_and_records(rt, kernel):
     """Duplicates must still resolve to the lowest original index although the sorted list visits
     them in another order; non-finite spheres keep their group always evaluated; the per-bounce
     records (original indices) equal the oracle's."""
@@ -98,13 +108,13 @@ def test_culled_ties_degenerates_and_records(rt):
     sph[59]["radius"] = np.inf
     sph[60]["radius"] = np.nan
     for profile in (0, 1):
-        acc, col, cnt = _render_gpu(rt, scene, 160, 96, profile=profile, kernel=CULLED, n_frames=3, depth=12)
+        acc, col, cnt = _render_gpu(rt, scene, 160, 96, profile=profile, kernel=kernel, n_frames=3, depth=12)
         cacc, ccol, crays = _render_cpu(scene, 160, 96, profile=profile, n_frames=3, depth=12)
         assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and cnt["rays"] == crays
     ubo = scene.camera.copy()
     ubo["frameCount"][0] = 2
     with rt.Renderer(160, 96) as r:
-        r.set_kernel(CULLED)
+        r.set_kernel(kernel)
         r.set_max_depth(12)
         r.upload_spheres(sph)
         r.set_uniforms(ubo)
@@ -114,12 +124,13 @@ def test_culled_ties_degenerates_and_records(rt):
     assert np.array_equal(_bits(light), _bits(clight))
 
 
-def test_culled_with_materials_and_reupload(rt):
+@BOTH
+def test_culled_with_materials_and_reupload(rt, kernel):
     scene = rt.Scene.generate(rt.KIND_RTIOW_MATERIALS, 0, 2)
     ubo = scene.camera.copy()
     ubo["frameCount"][0] = 1
     with rt.Renderer(256, 144) as r:
-        r.set_kernel(CULLED)
+        r.set_kernel(kernel)
         r.set_max_depth(16)
         r.set_scene(scene, frame_count=1)
         r.dispatch(2)
@@ -145,7 +156,8 @@ def test_culled_with_materials_and_reupload(rt):
         assert np.array_equal(_bits(acc3), _bits(cacc3))
 
 
-def test_culled_full_size_equals_brute_force(rt, rtiow_scene):
+@BOTH
+def test_culled_full_size_equals_brute_force(rt, rtiow_scene, kernel):
     """3840x2160: the culled kernel against the brute-force stream kernel over the whole image."""
     w, h = 3840, 2160
     with rt.Renderer(w, h) as r:
@@ -153,7 +165,7 @@ def test_culled_full_size_equals_brute_force(rt, rtiow_scene):
         r.dispatch(2)
         a0, c0, n0 = r.read_accum(), r.read_color(), r.counters()["rays"]
         r.reset_counters()
-        r.set_kernel(CULLED)
+        r.set_kernel(kernel)
         r.dispatch(2)
         a1, c1, n1 = r.read_accum(), r.read_color(), r.counters()["rays"]
     assert np.array_equal(_bits(a0), _bits(a1)) and np.array_equal(c0, c1) and n0 == n1
