@@ -1,0 +1,8 @@
+#!/bin/bash
+# One GPU-box call: tools/collect_profiles.sh for every bench workload.  usage: tools/gpu_profiles.sh TAG [workload ...]
+set -e
+tag=${1:-r02}; shift || true
+wls=${*:-rtiow4k default720p_d8 default1080p stress4096 interactive}
+for wl in $wls; do
+  bash tools/collect_profiles.sh "$tag" "$wl"
+done
