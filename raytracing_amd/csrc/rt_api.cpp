@@ -72,7 +72,7 @@ struct rt_context {
     RtSphereAos* d_spheres = nullptr;  // AoS copy
     float4* d_geom = nullptr;  // pair-packed sieve geometry
     float* d_radius = nullptr; // radii, padded
-    uint4* d_frags = nullptr;  // sphere-side operands of the matrix-core sieve, room for RT_MAX_MFMA_SPHERES
+    uint4* d_frags = nullptr;  // sphere-side operands of the matrix-core sieve, room for RT_MAX_MFMA_FAR_SPHERES
     bool have_frags = false;   // d_frags describes the uploaded spheres (false: too many of them)
     float2* d_materials = nullptr;  // material extension: {kind, param} per sphere
     int material_cap = 0;
@@ -444,7 +444,13 @@ void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* t
 // Whether this dispatch runs the sieve on the matrix cores (mode 3 of rt_launch_stream).
 bool wants_mfma(const rt_context* c, const RtParams& P)
 {
-    const bool can = c->have_frags && P.n_pad > 0 && P.n_pad <= RT_MAX_MFMA_SPHERES;
+    // up to RT_MAX_MFMA_SPHERES with the operands in LDS, beyond with the operands in global memory
+    static const bool far_ok = [] {
+        const char* e = getenv("RT_DEBUG_MFMA_FAR");  // development knob: 0 = scenes above RT_MAX_MFMA_SPHERES stay on the vector ALU
+        return !e || atoi(e) != 0;
+    }();
+    const int limit = far_ok || c->kernel == RT_KERNEL_STREAM_MFMA ? RT_MAX_MFMA_FAR_SPHERES : RT_MAX_MFMA_SPHERES;
+    const bool can = c->have_frags && P.n_pad > 0 && P.n_pad <= limit;
     static const int min_pad = [] {
         const char* e = getenv("RT_DEBUG_MFMA_MIN_SPHERES");  // development knob: smallest padded count RT_KERNEL_STREAM hands to the matrix cores
         return e ? atoi(e) : 64;
@@ -463,7 +469,8 @@ bool wants_mfma(const rt_context* c, const RtParams& P)
 void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const RtParams& P, int* blocks,
                         int* threads)
 {
-    const bool mfma = P.frags != nullptr;  // the operand fragments are staged in LDS too: larger workgroups share them
+    const bool far = P.frags != nullptr && P.n_pad > RT_MAX_MFMA_SPHERES;  // matrix-core sieve, operands left in global memory
+    const bool mfma = P.frags != nullptr && !far;  // the operand fragments are staged in LDS too: larger workgroups share them
     // matrix-core sieve: two waves per SIMD saturate it (measured: 8 waves per CU = 12 = 16); 256-thread
     // workgroups while two of them fit in LDS, else one of 512
     const int t_mfma = rt_stream_lds_bytes(P.n_lds, 256, true) * 2 <= kLdsPerCu ? 256 : 512;
@@ -647,7 +654,8 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     P.frags = mfma ? c->d_frags : nullptr;
     int blocks, threads;
     stream_geometry(c, P, &blocks, &threads);
-    if (rt_stream_lds_bytes(P.n_lds, threads, mfma) > kLdsPerCu)
+    const bool far = mfma && P.n_pad > RT_MAX_MFMA_SPHERES;
+    if (rt_stream_lds_bytes(P.n_lds, threads, mfma && !far) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
@@ -659,7 +667,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     int mode = c->kernel == RT_KERNEL_STREAM_SGPR || c->kernel == RT_KERNEL_STREAM_CULLED || c->kernel == RT_KERNEL_BVH ||
                        (c->kernel == RT_KERNEL_STREAM && P.n_pad <= RT_MAX_SGPR_SPHERES)
                    ? 1 : 0;
-    if (mfma) mode = 3;
+    if (mfma) mode = far ? 5 : 3;
     if (c->kernel == RT_KERNEL_STREAM_CULLED || c->kernel == RT_KERNEL_BVH) {
         bool on = false;
         const int rc = use_culled(c, &P, &on);
@@ -682,7 +690,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     }
     c->last_blocks = blocks;
     c->last_threads = threads;
-    c->last_mode = mode == 4 ? 6 : mode;
+    c->last_mode = mode == 4 ? 6 : mode == 5 ? 3 : mode;
     return RT_OK;
 }
 
@@ -824,8 +832,8 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     HIP_TRY(hipMemcpy(c->d_geom, geom.data(), (size_t)cap * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_radius, radius.data(), (size_t)cap * sizeof(float), hipMemcpyHostToDevice));
     c->have_frags = false;
-    if (cap <= RT_MAX_MFMA_SPHERES) {
-        if (!c->d_frags) HIP_TRY(hipMalloc(&c->d_frags, (size_t)RT_MAX_MFMA_SPHERES * 4 * sizeof(uint4)));
+    if (cap <= RT_MAX_MFMA_FAR_SPHERES) {
+        if (!c->d_frags) HIP_TRY(hipMalloc(&c->d_frags, (size_t)RT_MAX_MFMA_FAR_SPHERES * 4 * sizeof(uint4)));
         std::vector<uint32_t> frags;
         try {
             build_mfma_frags(host, &frags);

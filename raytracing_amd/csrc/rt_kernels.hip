@@ -1340,6 +1340,65 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
     return summary << (32 - nsg);
 }
 
+// As sieve_chunks_mfma for scenes whose sphere-side fragments do not fit in LDS beside the rest
+// (more than RT_MAX_MFMA_SPHERES spheres): `frag` points into GLOBAL memory (the fragments of a
+// 4096-sphere scene are 256 KiB, resident in L2), every wave streams them for itself, and the
+// loads run AHEAD chunks in front of the arithmetic through a ring of AHEAD register pairs.  The
+// loop is unrolled AHEAD times so that the ring is addressed statically; the chunks are taken in
+// runs of AHEAD, a run that overshoots `nsg` recomputes the last chunk and drops the result.
+template <int AHEAD>
+__device__ __forceinline__ uint32_t sieve_chunks_mfma_far(const v8bf* __restrict__ frag, int nsg, int lane,
+                                                          const MfmaRay& r, bool alive, bool has_last,
+                                                          uint32_t last_valid, uint32_t* wmask)
+{
+    uint32_t summary = 0;
+    v16f SA, TA, SB, TB;
+    v8bf q0[AHEAD], q1[AHEAD];
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {
+        const int cn = min(k, nsg - 1);
+        q0[k] = frag[cn * 128 + lane];
+        q1[k] = frag[cn * 128 + 64 + lane];
+    }
+    mfma_tile(q0[0], q1[0], r, 0, SA, TA);
+    for (int c0 = 0; c0 < nsg; c0 += AHEAD) {
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) {
+            const int c = c0 + k;
+            constexpr int dummy = 0;
+            (void)dummy;
+            const v8bf a0 = q0[k], a1 = q1[k];
+            const int cn = min(c + AHEAD, nsg - 1);
+            mfma_tile(a0, a1, r, 1, SB, TB);
+            // slot k is free once its second tile has been issued: chunk c + AHEAD goes there
+            q0[k] = frag[cn * 128 + lane];
+            q1[k] = frag[cn * 128 + 64 + lane];
+            const uint32_t m0 = tile_mask(SA, TA);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            }
+            mfma_tile(q0[(k + 1) % AHEAD], q1[(k + 1) % AHEAD], r, 0, SA, TA);
+            const uint32_t m1 = tile_mask(SB, TB);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            }
+            const v2u own = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
+            uint32_t cand = ~((own.x << 16) | own.y);
+            if (has_last && c == nsg - 1) cand &= last_valid;
+            if (!alive) cand = 0u;
+            if (c < nsg) {  // wave-uniform
+                wmask[c * 64 + lane] = cand;
+                summary = (summary << 1) | (cand != 0u ? 1u : 0u);
+            }
+        }
+    }
+    return summary << (32 - nsg);
+}
+
 // ------------------------------------------------- per-lane traversal (MODE 4)
 //
 // Trace() over the spatially sorted sphere list as a walk down an implicit 8-ary hierarchy, every
@@ -1506,13 +1565,15 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
 // 2 = as 1, over the spatially sorted sphere list with group culling: per 512 spheres the wave
 // first sieves the 64 bounding spheres of their groups of 8, ORs the result over its lanes, and
 // skips the groups no lane can touch.  3 = the sieve on the matrix cores.  4 = per-lane traversal
-// of the sorted list (trace_bvh).
+// of the sorted list (trace_bvh).  5 = as 3 for scenes of more than RT_MAX_MFMA_SPHERES spheres: the
+// sphere-side operands stay in global memory.
 template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
 {
     constexpr bool SGEOM = MODE == 1 || MODE == 2;
     constexpr bool CULL = MODE == 2;
-    constexpr bool MFMA = MODE == 3;
+    constexpr bool MFMA = MODE == 3 || MODE == 5;
+    constexpr bool FAR_FRAGS = MODE == 5;  // matrix-core sieve with its sphere-side operands left in global memory
     constexpr bool BVH = MODE == 4;
     constexpr bool SORTED = CULL || BVH;  // slots of the sorted list: P.perm maps them to the shader's indices
     extern __shared__ float4 smem[];
@@ -1529,7 +1590,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     // matrix-core sieve: the sphere-side operand fragments follow (128 x 16 bytes per chunk)
     uint4* frags = reinterpret_cast<uint4*>(radius + P.n_lds);
     // matrix-core sieve: the sphere-side operands; per-lane traversal: the bounding spheres of the groups
-    const int n_frag = MFMA ? P.n_lds * 4 : BVH ? P.n_bounds : 0;
+    const int n_frag = MFMA && !FAR_FRAGS ? P.n_lds * 4 : BVH ? P.n_bounds : 0;
     for (int i = threadIdx.x; i < n_frag; i += blockDim.x)
         frags[i] = BVH ? reinterpret_cast<const uint4*>(P.bounds)[i] : P.frags[i];
     __syncthreads();  // the only barrier: waves run independently from here on
@@ -1710,7 +1771,10 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                     wneed = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)need0) << 32) |
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)need1);
                 }
-                if constexpr (MFMA) {
+                if constexpr (FAR_FRAGS) {
+                    summary = sieve_chunks_mfma_far<RT_MFMA_AHEAD>(reinterpret_cast<const v8bf*>(P.frags) + sg * 128, nsg, lane, mr,
+                                                                   alive, sg + nsg == nch, P.last_chunk_valid, wmask);
+                } else if constexpr (MFMA) {
                     summary = sieve_chunks_mfma(reinterpret_cast<const v8bf*>(frags) + sg * 128, nsg, lane, mr, alive,
                                                 sg + nsg == nch, P.last_chunk_valid, wmask);
                 } else {
@@ -1861,9 +1925,10 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
 {
     extern __shared__ float4 smem[];
     const bool mfma = P.frags != nullptr;  // audit the matrix-core sieve instead
+    const bool far = mfma && P.n_pad > RT_MAX_MFMA_SPHERES;  // fragments read from global memory, as MODE 5 does
     uint4* frags = reinterpret_cast<uint4*>(smem + P.n_pad);
     for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) smem[i] = P.geom[i];
-    for (int i = threadIdx.x; i < (mfma ? P.n_pad * 4 : 0); i += blockDim.x) frags[i] = P.frags[i];
+    for (int i = threadIdx.x; i < (mfma && !far ? P.n_pad * 4 : 0); i += blockDim.x) frags[i] = P.frags[i];
     __syncthreads();
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = ray < n_rays;
@@ -1877,8 +1942,9 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
     const MfmaRay mr = mfma_ray(p, a_s);
     for (int ch = 0; ch < P.n_pad / RT_CHUNK; ch++) {
         const uint32_t rej =
-            mfma ? sieve_chunk_mfma(reinterpret_cast<const v8bf*>(frags) + ch * 128, threadIdx.x & 63, mr)
-                 : sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
+            far    ? sieve_chunk_mfma(reinterpret_cast<const v8bf*>(P.frags) + ch * 128, threadIdx.x & 63, mr)
+            : mfma ? sieve_chunk_mfma(reinterpret_cast<const v8bf*>(frags) + ch * 128, threadIdx.x & 63, mr)
+                   : sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
         for (int n = 0; n < RT_CHUNK; n++) {
             const int i = ch * RT_CHUNK + n;
             if (i >= P.sphere_count || !live) break;
@@ -2082,7 +2148,7 @@ size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int n_bounds)
 
 // mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
 // 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0), 4 = per-lane traversal (P.bounds/P.perm/P.n_bounds
-// set, P.n_lds != 0)
+// set, P.n_lds != 0), 5 = as 3 with the operands read from global memory (P.frags set, P.n_lds != 0)
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
@@ -2100,6 +2166,13 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
                          : launch_stream<false, true, 2>(P, blocks, threads, lds, st);
         return fused ? launch_stream<true, false, 2>(P, blocks, threads, lds, st)
                      : launch_stream<false, false, 2>(P, blocks, threads, lds, st);
+    }
+    if (mode == 5) {
+        if (record)
+            return fused ? launch_stream<true, true, 5>(P, blocks, threads, lds, st)
+                         : launch_stream<false, true, 5>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, false, 5>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 5>(P, blocks, threads, lds, st);
     }
     if (mode == 4) {
         if (record)
@@ -2205,7 +2278,7 @@ hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const fl
 hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
                                  hipStream_t st)
 {
-    const size_t lds = (size_t)P.n_pad * (sizeof(float4) + (P.frags ? 4 * sizeof(uint4) : 0));
+    const size_t lds = (size_t)P.n_pad * (sizeof(float4) + (P.frags && P.n_pad <= RT_MAX_MFMA_SPHERES ? 4 * sizeof(uint4) : 0));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_sieve_audit_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -31,6 +31,12 @@ constexpr float RT_SIEVE_MARGIN = 1.52587890625e-05f;
 // staged in LDS beside the rest.
 constexpr float RT_SIEVE_MARGIN_MFMA = 3.0517578125e-05f;
 constexpr int RT_MAX_MFMA_SPHERES = 1024;
+// Beyond that, while the rest of the geometry still fits in LDS, the fragments are streamed from
+// global memory, loaded this many chunks ahead of their use.
+constexpr int RT_MAX_MFMA_FAR_SPHERES = RT_MAX_LDS_SPHERES;
+#ifndef RT_MFMA_AHEAD
+#define RT_MFMA_AHEAD 2
+#endif
 // Largest workgroup of the stream kernel's vector-ALU instantiations: 8 waves per CU, two per SIMD,
 // which leaves each wave the whole register file (the LDS-geometry sieve wants more than the 128
 // registers of 1024-thread workgroups and spilled to scratch memory under that cap).

@@ -131,7 +131,7 @@ def _tangent_rays(spheres, origins, rng, per_origin):
 
 
 @pytest.mark.parametrize("sieve,kernel", [("vector", 2), ("matrix", 5)])
-@pytest.mark.parametrize("scene_name", ["default", "rtiow", "cube1000", "far"])
+@pytest.mark.parametrize("scene_name", ["default", "rtiow", "cube1000", "cube3000", "far"])
 def test_sieve_never_rejects_a_literal_candidate(rt, default_scene, rtiow_scene, scene_name, sieve, kernel):
     """The stream kernel rejects spheres with a cheap conservative test before it evaluates the
     shader's expressions: on the vector ALU (fma chains) or on the matrix cores (bf16-split
@@ -140,8 +140,8 @@ def test_sieve_never_rejects_a_literal_candidate(rt, default_scene, rtiow_scene,
     must still reject nearly everything the literal test rejects.  "far" is the default scene
     moved 3000 units from the origin, where the expanded form cancels hardest."""
     scene = {"default": default_scene, "rtiow": rtiow_scene}.get(scene_name)
-    if scene_name == "cube1000":
-        scene = rt.Scene.generate(rt.KIND_CUBE, 1000, 5)
+    if scene_name.startswith("cube"):  # cube3000: the matrix-core sieve streams its operands from global memory
+        scene = rt.Scene.generate(rt.KIND_CUBE, int(scene_name[4:]), 5)
     if scene_name == "far":
         scene = rt.Scene.default()
         shift = np.array([3000.0, -1700.0, 2500.0], np.float32)
