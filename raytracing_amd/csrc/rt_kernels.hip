@@ -1271,6 +1271,12 @@ __device__ __forceinline__ uint32_t sieve_chunk_mfma(const v8bf* frag, int lane,
     return (own.x << 16) | own.y;
 }
 
+// Vector instructions the scheduler is asked to place behind each MFMA of the pipelined sieve: a
+// tile's accumulators take 16 v_fma_f32 and 16 v_alignbit_b32 beside its 4 MFMAs.
+#ifndef RT_MFMA_VALU_GROUP
+#define RT_MFMA_VALU_GROUP 8
+#endif
+
 // The four MFMAs of one 32 x 32 tile (ray group g of a chunk).
 __device__ __forceinline__ void mfma_tile(v8bf a0, v8bf a1, const MfmaRay& r, int g, v16f& S, v16f& T)
 {
@@ -1285,6 +1291,7 @@ __device__ __forceinline__ void mfma_tile(v8bf a0, v8bf a1, const MfmaRay& r, in
 __device__ __forceinline__ uint32_t tile_mask(const v16f& S, const v16f& T)
 {
     uint32_t mask = 0;
+    // (one v_fma_f32 per accumulator register: measured, v_pk_fma_f32 on register pairs is 5 % slower here)
 #pragma unroll
     for (int v = 0; v < 16; v++)
         mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(S[v], S[v], T[v])), 31);
@@ -1317,14 +1324,14 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
         }
         mfma_tile(n0, n1, r, 0, SA, TA);
         const uint32_t m1 = tile_mask(SB, TB);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
         }
         a0 = n0;
         a1 = n1;
@@ -1377,14 +1384,14 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma_far(const v8bf* __restrict
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
             }
             mfma_tile(q0[(k + 1) % AHEAD], q1[(k + 1) % AHEAD], r, 0, SA, TA);
             const uint32_t m1 = tile_mask(SB, TB);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
             }
             const v2u own = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
             uint32_t cand = ~((own.x << 16) | own.y);
