@@ -71,10 +71,11 @@ def parse_args():
     p.add_argument("--workload", choices=list(WORKLOADS), default="rtiow4k")
     p.add_argument("--frames-per-step", type=int, default=None)
     p.add_argument("--profile", choices=["strict", "fused"], default="strict")
-    p.add_argument("--kernel", choices=["stream", "valu", "tile", "culled"], default="stream",
-                   help="stream: the brute-force kernel the metrics are quoted on (sieve on the matrix cores from 33 to "
-                        "1024 spheres); valu: the same with the sieve on the vector ALU; culled: over a spatially sorted "
-                        "sphere list, skipping groups no ray of a wave can touch (same image)")
+    p.add_argument("--kernel", choices=["stream", "valu", "tile", "culled", "bvh"], default="stream",
+                   help="stream: the brute-force kernel the metrics are quoted on (sieve on the matrix cores from 65 to "
+                        "4096 spheres); valu: the same with the sieve on the vector ALU; culled: over a spatially sorted "
+                        "sphere list, skipping groups no ray of a wave can touch; bvh: that list walked as a hierarchy "
+                        "by every lane on its own (culled and bvh: same image, not brute force)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg (0 = skip)")
     p.add_argument("--max-depth", type=int, default=None)
     p.add_argument("--materials", action="store_true",
@@ -168,7 +169,7 @@ def cpu_baseline(scene, size, profile, max_depth, seconds, interactive_frames=No
         rays += r
         frames += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or frames >= 64 or (interactive_frames is not None and frames >= len(interactive_frames)):
+        if dt >= seconds or (interactive_frames is not None and frames >= len(interactive_frames)):
             break
     sample = (f"{frames} whole frame(s) of the same {w}x{h} workload, depth {max_depth}, {rays} rays in {dt:.1f} s "
               f"(CPU oracle, {'fused' if profile else 'strict'} profile); " + lavapipe_probe())
@@ -225,10 +226,10 @@ def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key, sieve
                                "the split products run at the bf16 rate; `matrix_pipe` prices what is executed")
         out["matrix_pipe"] = {"achieved": executed, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (bf16, executed)",
                               "frac": executed / PEAK_BF16_TFLOPS, "flop_per_test": MFMA_FLOP_PER_TEST}
-    if args.kernel == "culled":
+    if args.kernel in ("culled", "bvh"):
         # whole groups of spheres are skipped: rays x sphereCount counts tests that were never made
         out["achieved"] = out["frac"] = None
-        out["note"] = (f"culled kernel: {achieved:.1f} TFLOP/s would be the brute-force-equivalent rate (rays x "
+        out["note"] = (f"{args.kernel} kernel: {achieved:.1f} TFLOP/s would be the brute-force-equivalent rate (rays x "
                        "sphereCount x 21 flop), not work this kernel executes")
     return out
 
@@ -242,7 +243,7 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
     w, h = wl["size"]
     scene, scene_text = make_scene(rt, wl["scene"], args.materials)
     profile = rt.PROFILE_FUSED if args.profile == "fused" else rt.PROFILE_STRICT
-    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED,
+    kernel = {"tile": rt.KERNEL_TILE, "culled": rt.KERNEL_STREAM_CULLED, "bvh": rt.KERNEL_BVH,
               "valu": rt.KERNEL_STREAM_SGPR}.get(args.kernel, rt.KERNEL_STREAM)
     fps = args.frames_per_step
 

@@ -8,23 +8,29 @@
 // Build with -ffp-contract=off: the only fused multiply-adds are the explicit ones of
 // the FUSED float profile, so every result is reproducible bit for bit on the CPU.
 //
-// Two kernels, same results:
+// Four kernels, same results:
 //   rt_tile_kernel   one wave per 8x8 tile, one lane per pixel, the sphere loop exactly as
 //                    the shader writes it.  The plain mapping, kept as the in-GPU cross-check.
 //   rt_stream_kernel persistent waves.  A lane whose pixel is finished takes the next pixel
 //                    from its wave's span (64-pixel spans drawn from per-XCD work queues), so all
 //                    64 lanes carry a live ray in almost every pass over the spheres, whatever
 //                    the spread of bounce counts.  The sphere loop is split in two:
-//                      sieve: for 32 spheres at a time, packed-f32 math on sphere PAIRS evaluates
-//                             a conservative form of the discriminant's sign and shifts it into a
-//                             per-lane mask: 8 packed ops + 2 shifts per pair = 5 instructions
-//                             per ray-sphere test, no branch (see sieve_pair);
+//                      sieve: for 32 spheres at a time a conservative form of the discriminant's
+//                             sign is shifted into a per-lane mask, no branch.  On the vector ALU,
+//                             packed-f32 math on sphere PAIRS: 5 instructions per ray-sphere test
+//                             (sieve_pair); on the matrix cores, the two dot products as exact
+//                             bf16-split MFMAs: 2 vector instructions per test (sieve_chunks_mfma);
 //                      walk : each lane then visits only its own candidates in index order and
 //                             evaluates the shader's expressions literally (sqrt, divide, t > 0,
 //                             t < best), so ties and rounding are the shader's.
-//                    The sieve reads pair-packed geometry through the scalar cache (SGPR
-//                    operands) or, for large scenes, from a copy staged once per workgroup in
-//                    LDS with wave-uniform ds_read_b128; the walk reads the LDS copy.
+//                    MODE picks the sieve and where its operands come from (scalar cache, LDS,
+//                    matrix-core fragments in LDS or streamed from global memory), or, not brute
+//                    force any more, a spatially sorted list with wave-level group culling or a
+//                    per-lane walk down a hierarchy of bounding spheres (trace_bvh).
+//   rt_lite_kernel   at most 64 spheres: one wave per tile, no queues, sieve + walk from LDS,
+//                    lanes run their pixel's frames back to back.
+//   rt_rows_kernel   at most 64 spheres, many frames of a small image: persistent waves that hand
+//                    out work path by path and add each pixel's frames in order through LDS.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -1,6 +1,6 @@
 // rt_static.hip -- rt_dispatch_static: one dispatch of the path-trace kernel that allocates
 // nothing, for callers that cannot call hipMalloc (code under HIP graph capture, tight serving
-// loops, harnesses that forbid it).  It runs the same kernels as rt_dispatch_frames; what a
+// loops, harnesses that forbid it).  It runs kernels rt_dispatch_frames runs too; what a
 // context keeps in device memory of its own between calls -- span counters, ray counters, the
 // repacked sieve geometry and radii -- lives here in one file-scope device array, `scratch`,
 // that every GPU the library runs on holds until the process ends.

@@ -66,8 +66,9 @@ def test_bench_single_rank_line(workload, unit):
     assert workload in line["config"]["workload"] and "model" not in line["config"]
 
 
-def test_bench_culled_kernel_does_not_claim_brute_force_flops():
-    res = subprocess.run([sys.executable, "bench.py", "--kernel", "culled", "--steps", "2", "--warmup", "1",
+@pytest.mark.parametrize("kernel", ["culled", "bvh"])
+def test_bench_culled_kernel_does_not_claim_brute_force_flops(kernel):
+    res = subprocess.run([sys.executable, "bench.py", "--kernel", kernel, "--steps", "2", "--warmup", "1",
                           "--frames-per-step", "2", "--cpu-seconds", "0"], cwd=ROOT, capture_output=True, text=True,
                          timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
