@@ -69,9 +69,9 @@ enum {
                                   path by path, (pixel, frame), and add each pixel's frames in order through
                                   LDS; RT_KERNEL_STREAM picks it for such scenes. */
     RT_KERNEL_BVH = 8          /* STREAM_CULLED's sorted sphere list walked as a hierarchy by every lane on its
-                                  own: blocks of 64 slots, their groups of 8, the spheres of a group, each level
-                                  behind a bounding sphere (readme.md:38, "BVH implementation"); same bits.
-                                  Same scene sizes as STREAM_CULLED. */
+                                  own: blocks of 64 slots and their groups of 8 behind axis-aligned boxes, the
+                                  spheres of a group behind the sieve (readme.md:38, "BVH implementation");
+                                  same bits.  Same scene sizes as STREAM_CULLED. */
 };
 
 /* When the accumulation texel is zeroed. */
@@ -229,14 +229,15 @@ int rt_debug_math(rt_context* ctx, int op, const float* a, const float* b, const
    passed.  No reference counterpart. */
 int rt_debug_sieve_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[4]);
 
-/* Test hook for RT_KERNEL_STREAM_CULLED and RT_KERNEL_BVH: runs their culling test on n_rays
-   caller-supplied rays against the bounding spheres of the sorted list's groups of 8 slots and
-   blocks of 64.  out[0]: (ray, sphere) pairs whose group or block was culled although the sphere's
-   literal discriminant (either float profile) was not negative -- must be 0; out[1]: (ray, group)
-   pairs culled; out[2]: (ray, group) pairs tested; out[3], out[4]: the same for blocks; out[5]:
-   literal hits that RT_KERNEL_BVH's distance test would prune (the sphere itself, its group or its
-   block) when the nearest hit so far is that very hit -- must be 0; out[6]: literal hits so
-   examined.  No reference counterpart. */
+/* Test hook for RT_KERNEL_STREAM_CULLED and RT_KERNEL_BVH: runs their culling tests on n_rays
+   caller-supplied rays: the former's bounding spheres of the sorted list's groups of 8 slots, the
+   latter's boxes of those groups and of the blocks of 64.  out[0]: (ray, sphere) pairs whose group
+   or block was dropped although the sphere can be hit (bounding spheres: literal discriminant not
+   negative; boxes: a positive root; either float profile) -- must be 0; out[1], out[2]: (ray, group)
+   pairs culled / tested by the bounding spheres; out[3], out[4]: (ray, node) pairs dropped /
+   examined by the boxes; out[5]: literal hits that RT_KERNEL_BVH's distance test would prune (the
+   sphere itself, its group's or its block's box) when the nearest hit so far is that very hit --
+   must be 0; out[6]: literal hits so examined.  No reference counterpart. */
 int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[7]);
 
 /* Test hook: the next stream-kernel launch of this context is not made; that dispatch returns

@@ -85,6 +85,7 @@ struct rt_context {
     float4* d_cgeom = nullptr;    // pair-packed sieve geometry of the sorted list
     float* d_cradius = nullptr;   // radii of the sorted list
     float4* d_bounds = nullptr;   // pair-packed bounding spheres of the groups of RT_CULL_GROUP slots
+    float4* d_boxes = nullptr;    // per-lane traversal: boxes of the groups, then of the blocks (3 float4 per pair)
     int* d_perm = nullptr;        // sorted slot -> index in d_spheres
     int cull_cap = 0;             // slots allocated
     int cull_count = -1;          // sphere_count the sorted copy was built for; -1 = none / stale
@@ -325,7 +326,8 @@ uint32_t morton10(uint32_t v)  // spread the low 10 bits of v three apart
 struct CulledScene {
     std::vector<float> geom;    // 4 floats per slot, pair-packed
     std::vector<float> radius;  // per slot
-    std::vector<float> bounds;  // 4 floats per group, pair-packed, padded to 64 groups; then RT_BVH_BLOCKS block bounds
+    std::vector<float> bounds;  // 4 floats per group, pair-packed, padded to 64 groups
+    std::vector<float> boxes;   // per-lane traversal: 6 floats per group, then per block (see build_boxes)
     std::vector<int> perm;      // per slot
 };
 
@@ -379,7 +381,7 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
     out->geom.assign((size_t)n_pad * 4, 0.f);
     out->radius.assign((size_t)n_pad, 0.f);
     out->perm.assign((size_t)n_pad, 0);
-    out->bounds.assign((size_t)(nbounds + RT_BVH_BLOCKS) * 4, 0.f);
+    out->bounds.assign((size_t)nbounds * 4, 0.f);
     auto put = [](std::vector<float>& v, int slot, float x, float y, float z, float w) {
         const size_t base = (size_t)(slot >> 1) * 8 + (slot & 1);
         v[base + 0] = x; v[base + 2] = y; v[base + 4] = z; v[base + 6] = w;
@@ -394,12 +396,8 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
             put(out->geom, k, 0.f, 0.f, 0.f, -inf);  // padding: rejected whatever the ray
         }
     }
-    // entries 0 .. nbounds-1: the groups of RT_CULL_GROUP slots; entries nbounds .. : the blocks of
-    // RT_BVH_BLOCK slots (per-lane traversal), by the same construction over all their members
-    for (int g = 0; g < nbounds + RT_BVH_BLOCKS; g++) {
-        const bool block = g >= nbounds;
-        const int first = block ? (g - nbounds) * RT_BVH_BLOCK : g * RT_CULL_GROUP;
-        const int end = std::min(count, first + (block ? RT_BVH_BLOCK : RT_CULL_GROUP));
+    for (int g = 0; g < nbounds; g++) {
+        const int first = g * RT_CULL_GROUP, end = std::min(count, first + RT_CULL_GROUP);
         if (first >= count) {
             put(out->bounds, g, 0.f, 0.f, 0.f, -inf);  // no spheres: never needed
             continue;
@@ -433,6 +431,54 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
         }
         const double Rb = A * std::sqrt(1.0 + 1.0 / 64.0) * (1.0 + 1e-9);
         put(out->bounds, g, cb[0], cb[1], cb[2], sieve_w(cb[0], cb[1], cb[2], Rb));
+    }
+
+    // Boxes for the per-lane traversal (RT_KERNEL_BVH; trace_bvh in rt_kernels.hip has the test and
+    // why it is conservative): entries 0 .. nbounds-1 the groups of RT_CULL_GROUP slots, entries
+    // nbounds .. nbounds+RT_BVH_BLOCKS-1 the blocks of RT_BVH_BLOCK slots.  The box of a node holds
+    // every member sphere with its radius enlarged by RT_BOX_PAD (|c| + r); the kernel adds
+    // RT_BOX_PAD |o| for its ray.  Stored as centre and half-width, pair-packed per axis: entries
+    // (2k, 2k+1) = {cx0, cx1, hx0, hx1}, {cy0, cy1, hy0, hy1}, {cz0, cz1, hz0, hz1}.  A node with a
+    // non-finite member gets half-width +inf (always entered), a node without spheres -inf (never).
+    const int nboxes = nbounds + RT_BVH_BLOCKS;
+    out->boxes.assign((size_t)nboxes * 6, 0.f);
+    for (int g = 0; g < nboxes; g++) {
+        const bool block = g >= nbounds;
+        const int first = block ? (g - nbounds) * RT_BVH_BLOCK : g * RT_CULL_GROUP;
+        const int end = std::min(count, first + (block ? RT_BVH_BLOCK : RT_CULL_GROUP));
+        float ctr[3] = {0.f, 0.f, 0.f}, half[3] = {-inf, -inf, -inf};
+        if (first < count) {
+            bool ok = true;
+            double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+            for (int k = first; k < end; k++) {
+                const RtSphereAos& s = src[keyed[k].second];
+                ok = ok && finite(s);
+                const double c[3] = {s.cx, s.cy, s.cz};
+                const double r = std::fabs((double)s.radius);
+                const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+                const double reach = r + (double)RT_BOX_PAD * (cn + r);
+                for (int a = 0; a < 3; a++) {
+                    blo[a] = std::min(blo[a], c[a] - reach);
+                    bhi[a] = std::max(bhi[a], c[a] + reach);
+                }
+            }
+            for (int a = 0; a < 3; a++) {
+                if (!ok) {
+                    half[a] = inf;
+                    continue;
+                }
+                ctr[a] = (float)(0.5 * (blo[a] + bhi[a]));
+                const double h = std::max(bhi[a] - (double)ctr[a], (double)ctr[a] - blo[a]) * (1.0 + 1e-6);
+                half[a] = (float)h;
+                if ((double)half[a] < h) half[a] = std::nextafter(half[a], inf);
+                if (!std::isfinite(ctr[a]) || !std::isfinite(half[a])) { ctr[a] = 0.f; half[a] = inf; }
+            }
+        }
+        float* dst = out->boxes.data() + (size_t)(g >> 1) * 12 + (g & 1);
+        for (int a = 0; a < 3; a++) {
+            dst[4 * a + 0] = ctr[a];
+            dst[4 * a + 2] = half[a];
+        }
     }
 }
 
@@ -507,19 +553,22 @@ int ensure_culled(rt_context* c, int count, int n_pad)
         if (c->d_cgeom) HIP_TRY(hipFree(c->d_cgeom));
         if (c->d_cradius) HIP_TRY(hipFree(c->d_cradius));
         if (c->d_bounds) HIP_TRY(hipFree(c->d_bounds));
+        if (c->d_boxes) HIP_TRY(hipFree(c->d_boxes));
         if (c->d_perm) HIP_TRY(hipFree(c->d_perm));
-        c->d_cgeom = nullptr; c->d_cradius = nullptr; c->d_bounds = nullptr; c->d_perm = nullptr;
+        c->d_cgeom = nullptr; c->d_cradius = nullptr; c->d_bounds = nullptr; c->d_boxes = nullptr; c->d_perm = nullptr;
         c->cull_cap = 0;
         const size_t nbounds = ((size_t)n_pad / RT_CULL_GROUP + 63) / 64 * 64;
         HIP_TRY(hipMalloc(&c->d_cgeom, (size_t)n_pad * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->d_cradius, (size_t)n_pad * sizeof(float)));
-        HIP_TRY(hipMalloc(&c->d_bounds, (nbounds + RT_BVH_BLOCKS) * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_bounds, nbounds * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->d_boxes, (nbounds + RT_BVH_BLOCKS) * 6 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_perm, (size_t)n_pad * sizeof(int)));
         c->cull_cap = n_pad;
     }
     HIP_TRY(hipMemcpy(c->d_cgeom, cs.geom.data(), cs.geom.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cradius, cs.radius.data(), cs.radius.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_bounds, cs.bounds.data(), cs.bounds.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_boxes, cs.boxes.data(), cs.boxes.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_perm, cs.perm.data(), cs.perm.size() * sizeof(int), hipMemcpyHostToDevice));
     c->cull_count = count;
     return RT_OK;
@@ -539,6 +588,7 @@ int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false)
     P->geom = c->d_cgeom;
     P->radius = c->d_cradius;
     P->bounds = c->d_bounds;
+    P->boxes = c->d_boxes;
     P->n_bounds = (P->n_pad / RT_CULL_GROUP + 63) / 64 * 64;
     P->perm = c->d_perm;
     *on = true;
@@ -673,7 +723,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         const int rc = use_culled(c, &P, &on);
         if (rc != RT_OK) return rc;
         if (on) mode = c->kernel == RT_KERNEL_BVH && P.n_pad <= RT_BVH_BLOCK * RT_BVH_BLOCKS ? 4 : 2;
-        if (mode == 4 && rt_stream_lds_bytes(P.n_lds, threads, false, P.n_bounds) > kLdsPerCu)
+        if (mode == 4 && rt_stream_lds_bytes(P.n_lds, threads, false, P.n_bounds * 3 / 2) > kLdsPerCu)
             return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     }
     hipError_t e = hipSuccess;
@@ -757,6 +807,7 @@ int rt_destroy(rt_context* c)
     if (c->d_cgeom) (void)hipFree(c->d_cgeom);
     if (c->d_cradius) (void)hipFree(c->d_cradius);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
+    if (c->d_boxes) (void)hipFree(c->d_boxes);
     if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);

@@ -1416,34 +1416,91 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma_far(const v8bf* __restrict
 //
 // Trace() over the spatially sorted sphere list as a walk down an implicit 8-ary hierarchy, every
 // lane on its own: blocks of RT_BVH_BLOCK = 64 slots, their 8 groups of RT_CULL_GROUP = 8 slots,
-// the 8 spheres of a group.  Blocks and groups carry the bounding spheres build_culled() makes
-// (conservative against every member's own sieve), tested with the sieve itself:
-//   - top: the block bounds (at most 64) are sieved by the whole wave from the scalar cache, one
-//     64-bit mask of blocks per lane;
-//   - then a lane takes its work one NODE at a time -- the next group of its open block, else the
-//     next block of its mask -- reads the node's 8 entries (group bounds, or spheres) from LDS at
-//     its own address (8 x ds_read_b128), and sieves them; the entries of a block that pass open
-//     its groups, the spheres of a group that pass get the shader's literal test at once.  Lanes
-//     on a block and lanes on a group run the same instructions; only the margin constant differs.
+// the 8 spheres of a group.  Blocks and groups carry axis-aligned boxes (build_culled() in
+// rt_api.cpp), spheres are tested with the sieve:
+//   - top: the boxes of the blocks (at most 64) are tested by the whole wave from the scalar
+//     cache, one 64-bit mask of blocks per lane;
+//   - then a lane takes its work one NODE at a time: with no group open it opens its next block --
+//     reads the boxes of the block's 8 groups from LDS at its own address and tests them -- and
+//     with a group open it reads the group's 8 spheres and sieves them; the spheres that pass get
+//     the shader's literal test at once.
 // What the wave-level OR of the culled kernel gives away to incoherent rays stays here: a lane
 // visits only what its own ray may touch, and of that only what lies in front of its origin and
-// not beyond the nearest hit it has found so far (bvh_pair).  Ties go to the lowest ORIGINAL index (test_sphere with
-// the slot -> index table), whatever the order of the visits.
-// The verdict on one pair of entries (spheres, or bounding spheres) for one ray: the sign bit of the
-// sieve's g as in sieve_pair, OR two tests on the same intermediate values that the brute-force
-// kernels have no use for.  With s = n.(o - c) and t = r^2 - |o - c|^2 + m (n = d/|d|, m the margin),
-// g = s^2 + t, and bh = (best t so far) * |d|:
+// not beyond the nearest hit it has found so far.  Ties go to the lowest ORIGINAL index
+// (test_sphere with the slot -> index table), whatever the order of the visits.
+//
+// Why nothing that can be hit is dropped (u = 2^-24, first order in u).  The shader's own t of a
+// sphere (c, r), times |d|, lies between the exact entry and exit distances of the sphere inflated
+// by E = 21u|o-c|^2 + 7u r^2 -- the error bound of its discriminant, see sieve_pair -- up to a few u
+// of |o - c|; so the hit point lies within sqrt(r^2 + E) <= r + 0.0012 (|o| + |c|) + 0.0007 r of c.
+//   Boxes: the host's box of a node holds every member with its radius enlarged by RT_BOX_PAD
+//   (|c| + r), the test below widens it by RT_BOX_PAD (|ox| + |oy| + |oz|) >= RT_BOX_PAD |o| for the ray at
+//   hand, RT_BOX_PAD = 0.002: the hit point is inside by at least 0.0008 (|o| + |c|) + 0.0013 r on
+//   every axis, against rounding in the slab arithmetic of a few u (|o| + |c| + h + t).  So the
+//   interval [tmin, tmax] the test computes holds t |d| with that much to spare at both ends, and
+//   "tmax < 0", "tmin > tmax" and "tmin > best |d|" (best = the nearest literal t so far, a tie
+//   included) are all false for a node with such a hit.  Direction components below 2^-40 are
+//   given the reciprocal 2^40: the interval then still covers every t up to 2^40 times the
+//   padding, far beyond the scene.
+//   Spheres: bvh_pair below.
+// rt_debug_cull_audit evaluates these very functions on caller-supplied rays.
+
+// Per-ray constants of the box test: unit direction n = d/|d|, t counted in units of n.
+struct BoxRay {
+    v2f ix, iy, iz;     // 1 / n, clamped to +-2^40
+    v2f ax, ay, az;     // |1 / n|
+    v2f ox, oy, oz;     // -o / n
+    v2f ex, ey, ez;     // RT_BOX_PAD (|ox| + |oy| + |oz|) |1 / n|
+};
+
+__device__ __forceinline__ BoxRay box_ray(const Path& p, float a)
+{
+    const float inv = __builtin_amdgcn_rsqf(a);
+    const float big = 1099511627776.0f;  // 2^40
+    const float pad = RT_BOX_PAD * (fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz));
+    BoxRay r;
+    const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(p.dx * inv), -big, big);
+    const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(p.dy * inv), -big, big);
+    const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(p.dz * inv), -big, big);
+    r.ix = v2f{ix, ix}; r.iy = v2f{iy, iy}; r.iz = v2f{iz, iz};
+    r.ax = v2f{fabsf(ix), fabsf(ix)}; r.ay = v2f{fabsf(iy), fabsf(iy)}; r.az = v2f{fabsf(iz), fabsf(iz)};
+    r.ox = v2f{-p.ox * ix, -p.ox * ix}; r.oy = v2f{-p.oy * iy, -p.oy * iy}; r.oz = v2f{-p.oz * iz, -p.oz * iz};
+    r.ex = v2f{pad * fabsf(ix), pad * fabsf(ix)};
+    r.ey = v2f{pad * fabsf(iy), pad * fabsf(iy)};
+    r.ez = v2f{pad * fabsf(iz), pad * fabsf(iz)};
+    return r;
+}
+
+// The verdict on one pair of boxes, X Y Z = {c0, c1, h0, h1} per axis: per axis the ray is inside
+// the slab for t in [tc - th, tc + th], tc = (c - o) / n, th = (h + pad) / |n|; the sign bit shifted
+// into `mask` is SET (rejected) when the three intervals have no common point, when they end
+// before t = 0, or when they begin after bh = best |d|.
+__device__ __forceinline__ void bvh_box_pair(uint32_t& mask, v4f X, v4f Y, v4f Z, const BoxRay& r, float bh)
+{
+    const v2f tcx = __builtin_elementwise_fma(v2f{X.x, X.y}, r.ix, r.ox), thx = __builtin_elementwise_fma(v2f{X.z, X.w}, r.ax, r.ex);
+    const v2f tcy = __builtin_elementwise_fma(v2f{Y.x, Y.y}, r.iy, r.oy), thy = __builtin_elementwise_fma(v2f{Y.z, Y.w}, r.ay, r.ey);
+    const v2f tcz = __builtin_elementwise_fma(v2f{Z.x, Z.y}, r.iz, r.oz), thz = __builtin_elementwise_fma(v2f{Z.z, Z.w}, r.az, r.ez);
+    const v2f lx = tcx - thx, hx = tcx + thx, ly = tcy - thy, hy = tcy + thy, lz = tcz - thz, hz = tcz + thz;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(lx[k], ly[k]), lz[k]);
+        const float tmax = __builtin_fminf(__builtin_fminf(hx[k], hy[k]), hz[k]);
+        const uint32_t verdict = __float_as_uint(tmax - tmin) | __float_as_uint(tmax) | __float_as_uint(bh - tmin);
+        mask = __builtin_amdgcn_alignbit(mask, verdict, 31);
+    }
+}
+
+// The verdict on one pair of spheres for one ray: the sign bit of the sieve's g as in sieve_pair,
+// OR two tests on the same intermediate values that the brute-force kernels have no use for.
+// With s = n.(o - c) and t = r^2 - |o - c|^2 + m (n = d/|d|, m the margin), g = s^2 + t, and
+// bh = (best t so far) * |d|:
 //   - behind:  s > 0 and t < 0 -- the origin lies outside the sphere (inflated by m) and the centre
 //     behind it: both roots are negative;
 //   - beyond:  s + bh < 0 and bh (bh + 2 s) - t > 0 -- the ray enters the inflated sphere only after
-//     bh: nothing in it can be as near as the hit already found (a tie included).
-// Why that is safe: the shader's own t of a sphere, times |d|, is never below the exact entry
-// distance into that sphere inflated by E = 21u|o-c|^2 + 7u r^2 (u = 2^-24; the error bound of its
-// discriminant), less a few u of |o - c|; the sieve inflates by m = 256u (o.o + c.c + r.r) >= 6 E, and
-// all rounding in s, t, bh and the expression above stays below 111u (o.o + c.c + r.r) of the 213u
-// that difference leaves.  A bounding sphere of build_culled(), inflated by its own margin
-// (2^-9 o.o on the ray's side), contains every member inflated by m, so what holds for its
-// entry distance holds for its members'.  bh = +inf (no hit yet) prunes nothing.
+//     bh: it cannot be hit as near as the hit already found (a tie included).
+// Safe because the sieve inflates by m = 256u (o.o + c.c + r.r) >= 6 E (E as above), and all rounding
+// in s, t, bh and the expression above stays below 111u (o.o + c.c + r.r) of the 213u that difference
+// leaves.  bh = +inf (no hit yet) prunes nothing.
 __device__ __forceinline__ void bvh_pair(uint32_t& mask, v4f A, v4f B, const SieveRay& r, v2f bh)
 {
     const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, w = {B.z, B.w};
@@ -1463,7 +1520,8 @@ __device__ __forceinline__ void bvh_pair(uint32_t& mask, v4f A, v4f B, const Sie
     }
 }
 
-// bh of bvh_pair for a ray: best * |d|, with |d| = a * rsq(a) as the sieve's normalisation has it.
+// bh of bvh_pair and bvh_box_pair for a ray: best * |d|, with |d| = a * rsq(a) as the sieve's
+// normalisation has it.
 __device__ __forceinline__ float bvh_reach(float best, float a)
 {
     return best * (a * __builtin_amdgcn_rsqf(a));
@@ -1471,80 +1529,96 @@ __device__ __forceinline__ float bvh_reach(float best, float a)
 
 #ifdef RT_COUNT_PASSES
 static __device__ unsigned long long g_bvh_count[2];  // experiment: wave-level steps, lane-level steps
-#define g_bvh_steps bvh_steps_
 #endif
 
+// lds_geom: the sorted pair-packed sieve geometry; lds_boxes: the boxes of the groups (P.n_bounds
+// entries, 3 float4 per pair); both in LDS.  The boxes of the blocks are read from P.boxes.
 template <bool FUSED>
 __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, const RtParams& P, const float4* lds_geom,
-                                          const float* lds_radius, int bounds_at, float& best, int& idx)
+                                          const float* lds_radius, const float4* lds_boxes, float& best, int& idx)
 {
 #ifdef RT_COUNT_PASSES
     unsigned bvh_steps_ = 0;
 #endif
     const SieveRay sr = sieve_ray(p, a, alive);
-    const SieveRay srb = sieve_ray(p, a, alive, RT_CULL_MARGIN_O);
-    // block bounds: entries P.n_bounds .. of P.bounds, 4 at a time from the scalar cache
+    const BoxRay br = box_ray(p, a);
+    // block boxes, 4 at a time from the scalar cache
     const int nblk = (P.n_pad + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK;
     const int n4 = (nblk + 3) >> 2;
-    ConstGeomPtr bb = (ConstGeomPtr)(const void*)(P.bounds) + P.n_bounds;
-    const v2f none = {__builtin_inff(), __builtin_inff()};
+    ConstGeomPtr bb = (ConstGeomPtr)(const void*)(P.boxes) + (P.n_bounds >> 1) * 3;
+    const float none = __builtin_inff();
     uint32_t rej0 = 0u, rej1 = 0u;
 #pragma unroll 1
     for (int n = 0; n < min(n4, 8); n++) {
-        bvh_pair(rej0, bb[4 * n], bb[4 * n + 1], srb, none);
-        bvh_pair(rej0, bb[4 * n + 2], bb[4 * n + 3], srb, none);
+        bvh_box_pair(rej0, bb[6 * n], bb[6 * n + 1], bb[6 * n + 2], br, none);
+        bvh_box_pair(rej0, bb[6 * n + 3], bb[6 * n + 4], bb[6 * n + 5], br, none);
     }
 #pragma unroll 1
     for (int n = 8; n < n4; n++) {
-        bvh_pair(rej1, bb[4 * n], bb[4 * n + 1], srb, none);
-        bvh_pair(rej1, bb[4 * n + 2], bb[4 * n + 3], srb, none);
+        bvh_box_pair(rej1, bb[6 * n], bb[6 * n + 1], bb[6 * n + 2], br, none);
+        bvh_box_pair(rej1, bb[6 * n + 3], bb[6 * n + 4], bb[6 * n + 5], br, none);
     }
     // bit (31 - n): block n (bm0) / block 32 + n (bm1) may be touched; what was not evaluated has no spheres
-    uint32_t bm0 = n4 > 0 ? ~rej0 << (32 - 4 * min(n4, 8)) : 0u;
-    uint32_t bm1 = n4 > 8 ? ~rej1 << (32 - 4 * (n4 - 8)) : 0u;
+    uint32_t bm0 = n4 > 0 && alive ? ~rej0 << (32 - 4 * min(n4, 8)) : 0u;
+    uint32_t bm1 = n4 > 8 && alive ? ~rej1 << (32 - 4 * (n4 - 8)) : 0u;
     uint32_t gm = 0;  // bit (31 - k): group k of the open block is still to be visited
     int blk = 0;
-    const v4f* base = reinterpret_cast<const v4f*>(lds_geom);
+    const v4f* geom = reinterpret_cast<const v4f*>(lds_geom);
+    const v4f* boxes = reinterpret_cast<const v4f*>(lds_boxes);
     const float* gf = reinterpret_cast<const float*>(lds_geom);
     for (;;) {
-        const bool leaf = gm != 0u;
-        const bool inner = !leaf && (bm0 | bm1) != 0u;
-        if (__ballot(leaf || inner) == 0ull) break;
+        // ---- lanes without an open group open their next block
+        const bool open = gm == 0u && (bm0 | bm1) != 0u;
+        if (__ballot(open) != 0ull) {
+            if (open) {
+                if (bm0 != 0u) {
+                    blk = __clz(bm0);
+                    bm0 &= ~(0x80000000u >> blk);
+                } else {
+                    const int k = __clz(bm1);
+                    bm1 &= ~(0x80000000u >> k);
+                    blk = 32 + k;
+                }
+                const v4f* g = boxes + blk * (RT_BVH_BLOCK / RT_CULL_GROUP / 2 * 3);  // 8 groups = 4 pairs = 12 float4
+                v4f e[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) e[k] = g[k];
+                const float reach = bvh_reach(best, a);
+                uint32_t rej = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) bvh_box_pair(rej, e[3 * k], e[3 * k + 1], e[3 * k + 2], br, reach);
+                gm = (~rej) << (32 - RT_CULL_GROUP);
+            }
 #ifdef RT_COUNT_PASSES
-        g_bvh_steps += (leaf || inner) ? 0x10001u : 0x10000u;  // experiment: wave steps << 16 | this lane's steps
+            bvh_steps_ += open ? 0x10001u : 0x10000u;  // experiment: wave steps << 16 | this lane's steps
 #endif
-        int node = 0;  // float4 index of the node's 8 entries
+        }
+        // ---- lanes with an open group sieve its next group of spheres
+        const bool leaf = gm != 0u;
+        if (__ballot(leaf) == 0ull) {
+            if (__ballot((bm0 | bm1) != 0u) == 0ull) break;
+            continue;
+        }
+#ifdef RT_COUNT_PASSES
+        bvh_steps_ += leaf ? 0x10001u : 0x10000u;
+#endif
         int grp = 0;
+        uint32_t cand = 0u;
         if (leaf) {
             const int k = __clz(gm);
             gm &= ~(0x80000000u >> k);
             grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + k;
-            node = grp * RT_CULL_GROUP;
-        } else if (inner) {
-            if (bm0 != 0u) {
-                blk = __clz(bm0);
-                bm0 &= ~(0x80000000u >> blk);
-            } else {
-                const int k = __clz(bm1);
-                bm1 &= ~(0x80000000u >> k);
-                blk = 32 + k;
-            }
-            node = bounds_at + blk * (RT_BVH_BLOCK / RT_CULL_GROUP);
+            const v4f* g = geom + grp * RT_CULL_GROUP;
+            v4f e[RT_CULL_GROUP];
+#pragma unroll
+            for (int k2 = 0; k2 < RT_CULL_GROUP; k2++) e[k2] = g[k2];
+            const float reach = bvh_reach(best, a);
+            const v2f bh = {reach, reach};
+            uint32_t rej = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < RT_CULL_GROUP / 2; k2++) bvh_pair(rej, e[2 * k2], e[2 * k2 + 1], sr, bh);
+            cand = (~rej) << (32 - RT_CULL_GROUP);  // bit (31 - k): sphere k of the group passed
         }
-        const v4f* g = base + node;
-        v4f e[RT_CULL_GROUP];
-#pragma unroll
-        for (int k = 0; k < RT_CULL_GROUP; k++) e[k] = g[k];
-        SieveRay s2 = sr;
-        s2.no2 = leaf ? sr.no2 : srb.no2;
-        const float reach = bvh_reach(best, a);
-        const v2f bh = {reach, reach};
-        uint32_t rej = 0;
-#pragma unroll
-        for (int k = 0; k < RT_CULL_GROUP / 2; k++) bvh_pair(rej, e[2 * k], e[2 * k + 1], s2, bh);
-        const uint32_t pass = (~rej) << (32 - RT_CULL_GROUP);  // bit (31 - k): entry k passed
-        if (inner) gm = pass;
-        uint32_t cand = leaf ? pass : 0u;
         while (__ballot(cand != 0u) != 0ull) {
             if (cand != 0u) {
                 const int b = __clz(cand);
@@ -1602,10 +1676,10 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     }
     // matrix-core sieve: the sphere-side operand fragments follow (128 x 16 bytes per chunk)
     uint4* frags = reinterpret_cast<uint4*>(radius + P.n_lds);
-    // matrix-core sieve: the sphere-side operands; per-lane traversal: the bounding spheres of the groups
-    const int n_frag = MFMA && !FAR_FRAGS ? P.n_lds * 4 : BVH ? P.n_bounds : 0;
+    // matrix-core sieve: the sphere-side operands; per-lane traversal: the boxes of the groups
+    const int n_frag = MFMA && !FAR_FRAGS ? P.n_lds * 4 : BVH ? P.n_bounds * 3 / 2 : 0;
     for (int i = threadIdx.x; i < n_frag; i += blockDim.x)
-        frags[i] = BVH ? reinterpret_cast<const uint4*>(P.bounds)[i] : P.frags[i];
+        frags[i] = BVH ? reinterpret_cast<const uint4*>(P.boxes)[i] : P.frags[i];
     __syncthreads();  // the only barrier: waves run independently from here on
     uint32_t* wmask = reinterpret_cast<uint32_t*>(frags + n_frag) + wave * (RT_SG_CHUNKS * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
@@ -1748,7 +1822,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         float best = RT_FLT_MAX;
         int idx = -1;
         if constexpr (BVH) {
-            trace_bvh<FUSED>(p, a, alive, P, smem, radius, (int)(reinterpret_cast<const float4*>(frags) - smem), best, idx);
+            trace_bvh<FUSED>(p, a, alive, P, smem, radius, reinterpret_cast<const float4*>(frags), best, idx);
             RT_MARK(t_walk)
         } else {
             SieveRay sr;
@@ -1985,11 +2059,12 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
 // the kernel does (per lane, before the OR over the wave) and, for every group it would cull,
 // the literal discriminant of the group's spheres under both float profiles.
 // out[0]: (ray, sphere) pairs culled with a non-negative discriminant (must stay 0);
-// out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs tested; out[3], out[4]: the same
-// for the blocks of RT_BVH_BLOCK slots the per-lane traversal tests first (with its "behind" test);
-// out[5]: spheres with a literal hit that the traversal's distance test would prune, itself or by
-// its group or block, when the nearest hit so far is that very hit (must stay 0); out[6]: literal
-// hits so examined.  blockDim.x = 256.
+// out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs tested; out[3], out[4]: (ray, node)
+// pairs the per-lane traversal's box test drops / examines, over groups and blocks (a node dropped
+// although a member has a literal hit counts into out[0]); out[5]: spheres with a literal hit that
+// the traversal's distance test would prune, itself or by the box of its group or block, when the
+// nearest hit so far is that very hit (must stay 0); out[6]: literal hits so examined.
+// blockDim.x = 256.
 __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, const float* rays, int n_rays,
                                                            unsigned long long* out)
 {
@@ -2024,45 +2099,44 @@ __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, co
             }
         }
     }
-    // the blocks of RT_BVH_BLOCK slots (per-lane traversal), evaluated as trace_bvh does
+    // The boxes of the per-lane traversal, groups and blocks alike, evaluated as trace_bvh does
+    // (no hit yet: bh = +inf).  A box is also dropped when it lies behind the origin, so what
+    // counts here is a hit: either root positive, the far one being what a dielectric sphere may take.
     unsigned bculled = 0, btested = 0;
+    const BoxRay br_s = box_ray(p, a_s), br_f = box_ray(p, a_f);
+    const v4f* box = reinterpret_cast<const v4f*>(P.boxes);
     const int nblk = (P.n_pad + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK;
-    for (int b0 = 0; b0 < nblk; b0 += RT_CHUNK) {
-        const int n4 = min(8, (nblk - b0 + 3) >> 2);
-        uint32_t rej = 0;
-        const v2f none = {__builtin_inff(), __builtin_inff()};
-        const v4f* bb = reinterpret_cast<const v4f*>(P.bounds) + P.n_bounds + b0;
-        for (int n = 0; n < n4; n++) {
-            bvh_pair(rej, bb[4 * n], bb[4 * n + 1], srb, none);
-            bvh_pair(rej, bb[4 * n + 2], bb[4 * n + 3], srb, none);
-        }
-        rej <<= 32 - 4 * n4;
-        for (int n = 0; n < RT_CHUNK && b0 + n < nblk && live; n++) {
-            const int first = (b0 + n) * RT_BVH_BLOCK;
-            if (first >= P.sphere_count) break;
-            btested++;
-            if (!((rej >> (31 - n)) & 1u)) continue;
-            bculled++;
-            // a block is also dropped when it lies behind the origin: what counts here is a hit
-            // (either root positive: the far one is what a dielectric sphere may take)
-            for (int k = first; k < first + RT_BVH_BLOCK && k < P.sphere_count; k++) {
-                const float4 g = *reinterpret_cast<const float4*>(P.spheres + P.perm[k]);
-                float ts = RT_FLT_MAX, tf = RT_FLT_MAX;
-                int is = -1, jf = -1;
-                test_sphere<false>(p, a_s, g.x, g.y, g.z, g.w, k, ts, is, true);
-                test_sphere<true>(p, a_f, g.x, g.y, g.z, g.w, k, tf, jf, true);
-                if (is >= 0 || jf >= 0) bad++;
-            }
+    auto box_rejects = [&](int entry, const BoxRay& br, float bh) {
+        uint32_t m = 0;
+        bvh_box_pair(m, box[(entry >> 1) * 3], box[(entry >> 1) * 3 + 1], box[(entry >> 1) * 3 + 2], br, bh);
+        return ((m >> (1 - (entry & 1))) & 1u) != 0u;
+    };
+    for (int node = 0; node < ngroups + nblk && live; node++) {
+        const bool block = node >= ngroups;
+        const int first = block ? (node - ngroups) * RT_BVH_BLOCK : node * RT_CULL_GROUP;
+        const int size = block ? RT_BVH_BLOCK : RT_CULL_GROUP;
+        if (first >= P.sphere_count) continue;
+        const int entry = block ? P.n_bounds + (node - ngroups) : node;
+        btested++;
+        const bool rej_s = box_rejects(entry, br_s, __builtin_inff()), rej_f = box_rejects(entry, br_f, __builtin_inff());
+        if (!rej_s && !rej_f) continue;
+        bculled++;
+        for (int k = first; k < first + size && k < P.sphere_count; k++) {
+            const float4 g = *reinterpret_cast<const float4*>(P.spheres + P.perm[k]);
+            float ts = RT_FLT_MAX, tf = RT_FLT_MAX;
+            int is = -1, jf = -1;
+            test_sphere<false>(p, a_s, g.x, g.y, g.z, g.w, k, ts, is, true);
+            test_sphere<true>(p, a_f, g.x, g.y, g.z, g.w, k, tf, jf, true);
+            if ((rej_s && is >= 0) || (rej_f && jf >= 0)) bad++;
         }
     }
-    // The distance test of the per-lane traversal (bvh_pair): with "best" set to a sphere's own
-    // literal t, neither the sphere nor its group nor its block may be rejected -- the sharpest case
-    // of "nothing as near as the hit found so far is pruned", a tie.  Both float profiles.
+    // The distance test of the per-lane traversal: with "best" set to a sphere's own literal t,
+    // neither the sphere (bvh_pair) nor the box of its group or of its block (bvh_box_pair) may be
+    // rejected -- the sharpest case of "nothing as near as the hit found so far is pruned", a tie.
+    // Both float profiles.
     unsigned pruned = 0, hits = 0;
     const SieveRay sr_s = sieve_ray(p, a_s, true), sr_f = sieve_ray(p, a_f, true);
-    const SieveRay srb_f = sieve_ray(p, a_f, true, RT_CULL_MARGIN_O);
     const v4f* geom = reinterpret_cast<const v4f*>(P.geom);
-    const v4f* bnd = reinterpret_cast<const v4f*>(P.bounds);
     for (int k = 0; k < P.sphere_count && live; k++) {
         const float4 g = *reinterpret_cast<const float4*>(P.spheres + P.perm[k]);
         float ts = RT_FLT_MAX, tf = RT_FLT_MAX;
@@ -2078,13 +2152,8 @@ __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, co
             uint32_t m = 0;
             bvh_pair(m, geom[(k >> 1) * 2], geom[(k >> 1) * 2 + 1], prof ? sr_f : sr_s, bh);
             bool rejected = ((m >> (1 - (k & 1))) & 1u) != 0u;
-            const int grp = k / RT_CULL_GROUP, blk = k / RT_BVH_BLOCK + P.n_bounds;
-            m = 0;
-            bvh_pair(m, bnd[(grp >> 1) * 2], bnd[(grp >> 1) * 2 + 1], prof ? srb_f : srb, bh);
-            rejected = rejected || ((m >> (1 - (grp & 1))) & 1u) != 0u;
-            m = 0;
-            bvh_pair(m, bnd[(blk >> 1) * 2], bnd[(blk >> 1) * 2 + 1], prof ? srb_f : srb, bh);
-            rejected = rejected || ((m >> (1 - (blk & 1))) & 1u) != 0u;
+            rejected = rejected || box_rejects(k / RT_CULL_GROUP, prof ? br_f : br_s, reach);
+            rejected = rejected || box_rejects(P.n_bounds + k / RT_BVH_BLOCK, prof ? br_f : br_s, reach);
             if (rejected) pruned++;
         }
     }
@@ -2153,21 +2222,21 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int n_bounds)
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4)
 {
     return (size_t)n_lds * (sizeof(float4) + sizeof(float) + (mfma ? 4 * sizeof(uint4) : 0)) +
-           (size_t)n_bounds * sizeof(float4) + (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
+           (size_t)extra_float4 * sizeof(float4) + (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
 }
 
 // mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
-// 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0), 4 = per-lane traversal (P.bounds/P.perm/P.n_bounds
+// 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0), 4 = per-lane traversal (P.boxes/P.perm/P.n_bounds
 // set, P.n_lds != 0), 5 = as 3 with the operands read from global memory (P.frags set, P.n_lds != 0)
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
     if (threads < 64 || threads % 64 != 0 || threads > (mode == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS))
         return hipErrorInvalidConfiguration;  // beyond the instantiation's launch bounds
-    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds : 0);
+    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0);
     static const size_t pad = [] {
         const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
         return e ? (size_t)atol(e) : (size_t)0;

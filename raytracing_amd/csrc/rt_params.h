@@ -52,10 +52,13 @@ constexpr int RT_MAX_MFMA_FAR_SPHERES = RT_MAX_LDS_SPHERES;
 // (2^-9; see build_culled in rt_api.cpp for why it is larger than the sieve's).
 constexpr int RT_CULL_GROUP = 8;
 constexpr float RT_CULL_MARGIN_O = 0.001953125f;
-// Per-lane traversal (RT_KERNEL_BVH): slots per block (8 groups), and the number of block entries
-// that follow the group bounds (RT_MAX_LDS_SPHERES / RT_BVH_BLOCK, two chunks of the sieve).
+// Per-lane traversal (RT_KERNEL_BVH): slots per block (8 groups), the number of block entries that
+// follow the group entries in RtParams::boxes (RT_MAX_LDS_SPHERES / RT_BVH_BLOCK), and the relative
+// padding of its boxes: a member sphere's radius grows by RT_BOX_PAD (|c| + r) on the host and by
+// RT_BOX_PAD |o| for the ray at hand (see trace_bvh in rt_kernels.hip).
 constexpr int RT_BVH_BLOCK = 64;
 constexpr int RT_BVH_BLOCKS = 64;
+constexpr float RT_BOX_PAD = 0.002f;
 // Pixels a wave takes from a work queue at a time (one 8x8 tile).
 #ifndef RT_SPAN_PIXELS
 #define RT_SPAN_PIXELS 64
@@ -110,8 +113,9 @@ struct RtParams {
     // culled kernel only: geom/radius above are the spatially sorted copies, and
     const float4* bounds;        // pair-packed like geom: bounding sphere of every group of 8 slots,
                                  // padded to a multiple of 64 groups with never-touched entries
-                                 // and after those the RT_BVH_BLOCKS bounding spheres of the blocks of 64 slots
     int n_bounds;                // group entries in `bounds` (a multiple of 64)
+    const float4* boxes;         // per-lane traversal: boxes of the n_bounds groups, then of RT_BVH_BLOCKS blocks of
+                                 // 64 slots; centre and half-width pair-packed per axis, 3 float4 per pair of entries
     const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8

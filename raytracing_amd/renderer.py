@@ -211,7 +211,7 @@ class Renderer:
         out = (C.c_uint64 * 7)()
         N.check(N.lib().rt_debug_cull_audit(self._h, arr.ctypes.data_as(C.c_void_p), arr.shape[0], out))
         return {"missed": int(out[0]), "culled": int(out[1]), "tested": int(out[2]),
-                "blocks_culled": int(out[3]), "blocks_tested": int(out[4]),
+                "boxes_culled": int(out[3]), "boxes_tested": int(out[4]),
                 "hits_pruned": int(out[5]), "hits": int(out[6])}
 
     def debug_math(self, op: int, a, b=None, c=None) -> np.ndarray:

@@ -54,7 +54,7 @@ def test_group_test_never_culls_a_literal_candidate(rt, default_scene, rtiow_sce
     assert res["missed"] == 0, res
     assert res["tested"] > 0 and res["culled"] > 0.1 * res["tested"], res
     assert res["hits"] > 1000 and res["hits_pruned"] == 0, res
-    assert res["blocks_tested"] > 0 and (len(sph) < 128 or res["blocks_culled"] > 0.02 * res["blocks_tested"]), res
+    assert res["boxes_tested"] > 0 and res["boxes_culled"] > 0.1 * res["boxes_tested"], res
 
 
 @BOTH
