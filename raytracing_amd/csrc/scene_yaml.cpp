@@ -31,6 +31,16 @@ struct Parser {
     size_t pos = 0;
     std::string error;
 
+    // Nesting of flow sequences and of blocks: the schema needs 3 levels; a hostile file of a few
+    // hundred thousand '[' or '- - - ...' must end in an error, not in a stack overflow.
+    static constexpr int kMaxDepth = 64;
+    int depth = 0;
+    struct Nest {
+        int& d;
+        explicit Nest(int& depth) : d(depth) { d++; }
+        ~Nest() { d--; }
+    };
+
     bool fail(int line, const std::string& what)
     {
         if (error.empty()) error = "line " + std::to_string(line) + ": " + what;
@@ -63,6 +73,8 @@ struct Parser {
 
     bool parse_flow(const std::string& t, size_t& i, int line, Node* out)
     {
+        Nest nest(depth);
+        if (depth > kMaxDepth) return fail(line, "nesting too deep");
         while (i < t.size() && (t[i] == ' ' || t[i] == '\t')) i++;
         if (i < t.size() && t[i] == '[') {
             out->kind = Node::Sequence;
@@ -105,6 +117,8 @@ struct Parser {
 
     bool parse_block(Node* out)
     {
+        Nest nest(depth);
+        if (depth > kMaxDepth) return fail(lines[pos].number, "nesting too deep");
         const Line first = lines[pos];
         if (is_dash(first.text)) return parse_sequence(first.indent, out);
         if (key_length(first.text)) return parse_map(first.indent, out);

@@ -105,6 +105,8 @@ camera: [[0, 1, 2], [0, 0, 1], [-1, 0, 0], [0, 1, 0], 1, 0]
     "spheres: [[[0,0,x],1,[1,1,1]]]\ncamera: [[0,0,0],[0,0,1],[1,0,0],[0,1,0],1,0]",  # not a number
     "spheres: []\ncamera: [[0,0,0],[0,0,1],[1,0,0],[0,1,0],1.5,0]",        # sphereCount must be an int
     "spheres: [[[0,0,0],1,[1,1,1]]\ncamera: []",                           # unterminated flow sequence
+    "spheres: " + "[" * 300000,                                            # nesting far beyond the schema's: an error,
+    "spheres:\n  " + "- " * 200000 + "1",                                  # not a stack overflow
 ])
 def test_malformed_scenes_are_rejected(text):
     with pytest.raises(rt.RtError) as e:
