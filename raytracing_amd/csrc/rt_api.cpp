@@ -294,20 +294,11 @@ void build_mfma_frags(const std::vector<RtSphereAos>& padded, std::vector<uint32
             }
 }
 
-uint32_t morton10(uint32_t v)  // spread the low 10 bits of v three apart
-{
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
 // The sorted copy of the first `count` spheres for RT_KERNEL_STREAM_CULLED.
 //
 // Order: spheres much larger than the typical one (and any with a non-finite entry) first, the
-// rest along a Morton curve through their centres, so that every group of RT_CULL_GROUP
-// consecutive slots is compact.  Each group gets a bounding sphere (c_b, R_b); the kernel skips a
+// rest by recursive median splits of their centres, so that every block of RT_BVH_BLOCK and every
+// group of RT_CULL_GROUP consecutive slots is compact.  Each group gets a bounding sphere (c_b, R_b); the kernel skips a
 // group when its sieve, run on the bounding sphere with the margin RT_CULL_MARGIN_O on o.o,
 // rejects it for every ray of the wave.
 //
@@ -347,34 +338,57 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
         std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
         median = radii[radii.size() / 2];
     }
-    std::vector<char> big(count, 0);
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    // big ones (and any with a non-finite entry) first, in index order
+    std::vector<std::pair<uint32_t, int>> keyed;
+    keyed.reserve(count);
+    std::vector<int> rest;
     for (int i = 0; i < count; i++) {
-        const RtSphereAos& s = src[i];
-        big[i] = !finite(s) || std::fabs(s.radius) > 4.0f * median;
-        if (big[i]) continue;
-        const double c[3] = {s.cx, s.cy, s.cz};
-        for (int k = 0; k < 3; k++) {
-            lo[k] = std::min(lo[k], c[k]);
-            hi[k] = std::max(hi[k], c[k]);
-        }
+        if (!finite(src[i]) || std::fabs(src[i].radius) > 4.0f * median)
+            keyed.push_back({0u, i});
+        else
+            rest.push_back(i);
     }
-    std::vector<std::pair<uint32_t, int>> keyed(count);
-    for (int i = 0; i < count; i++) {
-        uint32_t key = 0;
-        if (!big[i]) {
-            const double c[3] = {src[i].cx, src[i].cy, src[i].cz};
-            uint32_t q[3];
-            for (int k = 0; k < 3; k++) {
-                const double span = hi[k] - lo[k];
-                const double t = span > 0 ? (c[k] - lo[k]) / span : 0.0;
-                q[k] = (uint32_t)std::min(1023.0, std::max(0.0, t * 1023.0));
+    // The rest: recursive median splits along the longest axis of the centres, cut at the slot
+    // boundaries of blocks (RT_BVH_BLOCK slots) first and of groups (RT_CULL_GROUP) inside them, so
+    // that every block and every group is a compact cell of a k-d partition.  (Runs of a Morton
+    // curve, the first version, are not: 64 consecutive points of a 22 x 22 grid came out as
+    // rectangles up to 22 x 8 that overlapped one another.)
+    {
+        const int base = (int)keyed.size();  // slot of rest[0]
+        auto coord = [&](int i, int axis) { return axis == 0 ? src[i].cx : axis == 1 ? src[i].cy : src[i].cz; };
+        struct Range { int lo, hi, unit; };
+        std::vector<Range> todo{{0, (int)rest.size(), RT_BVH_BLOCK}};
+        while (!todo.empty()) {
+            const Range r = todo.back();
+            todo.pop_back();
+            if (r.hi - r.lo <= 1) continue;
+            // slot boundaries (multiples of unit in absolute slots) strictly inside the range
+            const int first = ((base + r.lo) / r.unit + 1) * r.unit - base;
+            const int nb = first < r.hi ? (r.hi - 1 - first) / r.unit + 1 : 0;
+            if (nb == 0) {
+                if (r.unit > RT_CULL_GROUP) todo.push_back({r.lo, r.hi, RT_CULL_GROUP});
+                else std::sort(rest.begin() + r.lo, rest.begin() + r.hi);  // inside a group: index order
+                continue;
             }
-            key = 1u + (morton10(q[0]) | (morton10(q[1]) << 1) | (morton10(q[2]) << 2));
+            const int mid = first + (nb / 2) * r.unit;
+            float lo3[3] = {inf, inf, inf}, hi3[3] = {-inf, -inf, -inf};
+            for (int k = r.lo; k < r.hi; k++)
+                for (int a = 0; a < 3; a++) {
+                    lo3[a] = std::min(lo3[a], coord(rest[k], a));
+                    hi3[a] = std::max(hi3[a], coord(rest[k], a));
+                }
+            int axis = 0;
+            for (int a = 1; a < 3; a++)
+                if (hi3[a] - lo3[a] > hi3[axis] - lo3[axis]) axis = a;
+            std::nth_element(rest.begin() + r.lo, rest.begin() + mid, rest.begin() + r.hi, [&](int x, int y) {
+                const float cx = coord(x, axis), cy = coord(y, axis);
+                return cx < cy || (cx == cy && x < y);
+            });
+            todo.push_back({r.lo, mid, r.unit});
+            todo.push_back({mid, r.hi, r.unit});
         }
-        keyed[i] = {key, i};
+        for (int i : rest) keyed.push_back({1u, i});
     }
-    std::sort(keyed.begin(), keyed.end());  // ties by index: the order is a function of the scene alone
 
     const int ngroups = n_pad / RT_CULL_GROUP;
     const int nbounds = (ngroups + 63) / 64 * 64;
@@ -1235,11 +1249,13 @@ int rt_get_counters(rt_context* c, rt_counters* out)
     unsigned long long passes = 0;
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passes += slots[i * RT_RAY_SLOT_STRIDE + 1];
     fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)rays / passes : 0.0);
-    unsigned long long bvh[2];
+    unsigned long long bvh[4];
     rt_bvh_step_counts(bvh);
     if (bvh[0])
-        fprintf(stderr, "per-lane traversal: %.2f steps per pass, %.2f of 64 lanes at work in a step\n",
-                (double)bvh[0] / passes, (double)bvh[1] / bvh[0]);
+        fprintf(stderr, "per-lane traversal: %.2f steps per pass, %.2f of 64 lanes at work in a step; per ray %.2f blocks opened, "
+                        "%.2f groups sieved, %.2f literal tests\n",
+                (double)bvh[0] / passes, (double)bvh[1] / bvh[0], (double)bvh[2] / rays, (double)(bvh[1] - bvh[2]) / rays,
+                (double)bvh[3] / rays);
 #endif
 #ifdef RT_PHASE_TIMERS
     {

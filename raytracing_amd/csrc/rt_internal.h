@@ -18,7 +18,7 @@ hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_
 hipError_t rt_launch_rows(const RtParams& P, bool fused, int blocks, hipStream_t st);
 size_t rt_rows_lds_bytes(int threads);
 #ifdef RT_COUNT_PASSES
-void rt_bvh_step_counts(unsigned long long out[2]);  // experiment build: traversal steps since the last call
+void rt_bvh_step_counts(unsigned long long out[4]);  // experiment build: traversal steps since the last call
 #endif
 hipError_t rt_launch_resolve(const float4* accum, uint32_t* color, int width, int x_max, int y0,
                              int y1, float divisor, hipStream_t st);

@@ -1418,8 +1418,8 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma_far(const v8bf* __restrict
 // lane on its own: blocks of RT_BVH_BLOCK = 64 slots, their 8 groups of RT_CULL_GROUP = 8 slots,
 // the 8 spheres of a group.  Blocks and groups carry axis-aligned boxes (build_culled() in
 // rt_api.cpp), spheres are tested with the sieve:
-//   - top: the boxes of the blocks (at most 64) are tested by the whole wave from the scalar
-//     cache, one 64-bit mask of blocks per lane;
+//   - top: the whole wave sieves group 0 (the largest spheres), then tests the boxes of the blocks
+//     (at most 64) from the scalar cache, one 64-bit mask of blocks per lane;
 //   - then a lane takes its work one NODE at a time: with no group open it opens its next block --
 //     reads the boxes of the block's 8 groups from LDS at its own address and tests them -- and
 //     with a group open it reads the group's 8 spheres and sieves them; the spheres that pass get
@@ -1527,8 +1527,12 @@ __device__ __forceinline__ float bvh_reach(float best, float a)
     return best * (a * __builtin_amdgcn_rsqf(a));
 }
 
+// (The traversal is a chain of dependent LDS gathers and gains from every wave it can get: 13.9 /
+// 18.9 / 22.9 / 26.3 Grays/s at 4 / 6 / 8 / 12 waves per CU on the 484-sphere scene.  Its ~150
+// registers allow 12; capped at 128 registers for 16 waves it spills 46 of them.)
+
 #ifdef RT_COUNT_PASSES
-static __device__ unsigned long long g_bvh_count[2];  // experiment: wave-level steps, lane-level steps
+static __device__ unsigned long long g_bvh_count[4];  // experiment: wave-level steps, lane-level steps; of the latter: blocks opened, literal tests
 #endif
 
 // lds_geom: the sorted pair-packed sieve geometry; lds_boxes: the boxes of the groups (P.n_bounds
@@ -1538,34 +1542,53 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
                                           const float* lds_radius, const float4* lds_boxes, float& best, int& idx)
 {
 #ifdef RT_COUNT_PASSES
-    unsigned bvh_steps_ = 0;
+    unsigned bvh_steps_ = 0, bvh_inner_ = 0, bvh_tests_ = 0;
 #endif
     const SieveRay sr = sieve_ray(p, a, alive);
     const BoxRay br = box_ray(p, a);
+    const v4f* geom = reinterpret_cast<const v4f*>(lds_geom);
+    const v4f* boxes = reinterpret_cast<const v4f*>(lds_boxes);
+    const float* gf = reinterpret_cast<const float*>(lds_geom);
+    // Group 0 first, by the whole wave: the sorted list begins with the scene's largest spheres (a
+    // ground sphere, say), and a hit on one of them lets the distance test drop whole blocks below.
+    {
+        const v2f none2 = {__builtin_inff(), __builtin_inff()};
+        uint32_t rej = 0;
+#pragma unroll
+        for (int k = 0; k < RT_CULL_GROUP / 2; k++) bvh_pair(rej, geom[2 * k], geom[2 * k + 1], sr, none2);
+        uint32_t cand = (~rej) << (32 - RT_CULL_GROUP);
+        while (__ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int i = __clz(cand);
+                cand &= ~(0x80000000u >> i);
+                bool far_root = false;
+                if (P.materials != nullptr) far_root = P.materials[P.perm[i]].x == 3.0f;  // wave-uniform branch
+                const float* f = gf + (i >> 1) * 8 + (i & 1);
+                test_sphere<FUSED>(p, a, f[0], f[2], f[4], lds_radius[i], i, best, idx, far_root, P.perm);
+            }
+        }
+    }
     // block boxes, 4 at a time from the scalar cache
     const int nblk = (P.n_pad + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK;
     const int n4 = (nblk + 3) >> 2;
     ConstGeomPtr bb = (ConstGeomPtr)(const void*)(P.boxes) + (P.n_bounds >> 1) * 3;
-    const float none = __builtin_inff();
+    const float reach0 = bvh_reach(best, a);
     uint32_t rej0 = 0u, rej1 = 0u;
 #pragma unroll 1
     for (int n = 0; n < min(n4, 8); n++) {
-        bvh_box_pair(rej0, bb[6 * n], bb[6 * n + 1], bb[6 * n + 2], br, none);
-        bvh_box_pair(rej0, bb[6 * n + 3], bb[6 * n + 4], bb[6 * n + 5], br, none);
+        bvh_box_pair(rej0, bb[6 * n], bb[6 * n + 1], bb[6 * n + 2], br, reach0);
+        bvh_box_pair(rej0, bb[6 * n + 3], bb[6 * n + 4], bb[6 * n + 5], br, reach0);
     }
 #pragma unroll 1
     for (int n = 8; n < n4; n++) {
-        bvh_box_pair(rej1, bb[6 * n], bb[6 * n + 1], bb[6 * n + 2], br, none);
-        bvh_box_pair(rej1, bb[6 * n + 3], bb[6 * n + 4], bb[6 * n + 5], br, none);
+        bvh_box_pair(rej1, bb[6 * n], bb[6 * n + 1], bb[6 * n + 2], br, reach0);
+        bvh_box_pair(rej1, bb[6 * n + 3], bb[6 * n + 4], bb[6 * n + 5], br, reach0);
     }
     // bit (31 - n): block n (bm0) / block 32 + n (bm1) may be touched; what was not evaluated has no spheres
     uint32_t bm0 = n4 > 0 && alive ? ~rej0 << (32 - 4 * min(n4, 8)) : 0u;
     uint32_t bm1 = n4 > 8 && alive ? ~rej1 << (32 - 4 * (n4 - 8)) : 0u;
     uint32_t gm = 0;  // bit (31 - k): group k of the open block is still to be visited
     int blk = 0;
-    const v4f* geom = reinterpret_cast<const v4f*>(lds_geom);
-    const v4f* boxes = reinterpret_cast<const v4f*>(lds_boxes);
-    const float* gf = reinterpret_cast<const float*>(lds_geom);
     for (;;) {
         // ---- lanes without an open group open their next block
         const bool open = gm == 0u && (bm0 | bm1) != 0u;
@@ -1588,9 +1611,11 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
 #pragma unroll
                 for (int k = 0; k < 4; k++) bvh_box_pair(rej, e[3 * k], e[3 * k + 1], e[3 * k + 2], br, reach);
                 gm = (~rej) << (32 - RT_CULL_GROUP);
+                if (blk == 0) gm &= 0x7fffffffu;  // group 0 has been dealt with
             }
 #ifdef RT_COUNT_PASSES
             bvh_steps_ += open ? 0x10001u : 0x10000u;  // experiment: wave steps << 16 | this lane's steps
+            bvh_inner_ += open ? 1u : 0u;
 #endif
         }
         // ---- lanes with an open group sieve its next group of spheres
@@ -1628,16 +1653,25 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
                 if (P.materials != nullptr) far_root = P.materials[P.perm[i]].x == 3.0f;  // wave-uniform branch
                 const float* f = gf + (i >> 1) * 8 + (i & 1);
                 test_sphere<FUSED>(p, a, f[0], f[2], f[4], lds_radius[i], i, best, idx, far_root, P.perm);
+#ifdef RT_COUNT_PASSES
+                bvh_tests_++;
+#endif
             }
         }
     }
 #ifdef RT_COUNT_PASSES
-    unsigned long long lanes = bvh_steps_ & 0xffffu;
+    unsigned long long lanes = bvh_steps_ & 0xffffu, inner = bvh_inner_, tests = bvh_tests_;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lanes += __shfl_down(lanes, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        lanes += __shfl_down(lanes, off, 64);
+        inner += __shfl_down(inner, off, 64);
+        tests += __shfl_down(tests, off, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&g_bvh_count[0], (unsigned long long)(bvh_steps_ >> 16));
         atomicAdd(&g_bvh_count[1], lanes);
+        atomicAdd(&g_bvh_count[2], inner);
+        atomicAdd(&g_bvh_count[3], tests);
     }
 #endif
 }
@@ -2292,11 +2326,11 @@ hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays
 }
 
 #ifdef RT_COUNT_PASSES
-void rt_bvh_step_counts(unsigned long long out[2])
+void rt_bvh_step_counts(unsigned long long out[4])
 {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_count), 16);
-    const unsigned long long zero[2] = {0, 0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_count), zero, 16);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_count), 32);
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_count), zero, 32);
 }
 #endif
 
