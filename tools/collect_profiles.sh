@@ -2,11 +2,18 @@
 # Run on the GPU box (through gpurun): kernel statistics and hardware counters of one bench.py workload.
 # Separate rocprofv3 runs (timing; FETCH_SIZE; WRITE_SIZE; SQ + GRBM counters), each under its own time limit.
 # Results land in gpurun_out/prof/<tag>/<workload>/; tools/summarise_profiles.py turns them into profiles/.
-#   usage: tools/collect_profiles.sh TAG WORKLOAD [more bench.py arguments]
+#   usage: tools/collect_profiles.sh TAG WORKLOAD [more bench.py arguments]   (with --kernel K the results go to <WORKLOAD>_K)
 set -e
 tag=$1; wl=$2; shift 2
 root=$(pwd)
-out=$root/gpurun_out/prof/$tag/$wl
+# a run with "--kernel K" lands in <workload>_K
+label=$wl
+prev=""
+for a in "$@"; do
+  if [ "$prev" = "--kernel" ]; then label=${wl}_$a; fi
+  prev=$a
+done
+out=$root/gpurun_out/prof/$tag/$label
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 args="--workload $wl --cpu-seconds 0 $*"
@@ -29,4 +36,4 @@ timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 # the unprofiled line of the same command, for the record next to the profiled one
 timeout -k 10 300 python3 bench.py $args > "$out/bench_plain.log" 2>&1
 grep '^{' "$out/bench_plain.log" > "$out/bench_line_plain.json"
-echo "collected $wl"
+echo "collected $label"

@@ -74,7 +74,9 @@ def one(tag, wl, pmc_all):
            "counters": counters, "duration_ns": durations}
     json.dump(rec, open(os.path.join(dst, f"{tag}_{wl}_counters.json"), "w"), indent=1)
 
-    key = f"{wl}_stream_strict"
+    # a label "<workload>_<kernel>" comes from a run with --kernel <kernel>; bench.py's key is <workload>_<kernel>_<profile>
+    known = [k for k in ("bvh", "culled", "valu", "tile") if wl.endswith("_" + k)]
+    key = f"{wl}_strict" if known else f"{wl}_stream_strict"
     out = {}
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         out["fetch_bytes_per_launch"] = counters["FETCH_SIZE"] * 1024 * 2
@@ -91,7 +93,7 @@ def one(tag, wl, pmc_all):
             # cycles, summed over the SIMDs, in which the matrix pipe works (32 per v_mfma_f32_32x32x16_bf16)
             out["mfma_busy"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (durations["SQ_VALU_MFMA_BUSY_CYCLES"] * out["clock_ghz"])
             out["mfma_insts_per_launch"] = counters.get("SQ_INSTS_MFMA")
-    if line["roofline"]["bound"] == "valu":
+    if line["roofline"]["bound"] == "valu" and line["roofline"]["achieved"] is not None:
         tests_per_launch = (line["roofline"]["achieved"] * 1e12 * line["roofline"]["kernel_ms_per_launch"] * 1e-3
                             / line["roofline"]["flop_per_test"])
         out["executed_flop_frac"] = (tests_per_launch * EXECUTED_FLOP_PER_TEST / (line["roofline"]["kernel_ms_per_launch"] * 1e-3)
