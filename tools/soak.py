@@ -14,7 +14,8 @@ import raytracing_amd as rt  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-scenes = [rt.Scene.default(), rt.Scene.generate(rt.KIND_RTIOW, 0, 7), rt.Scene.generate(rt.KIND_CUBE, 700, 3)]
+scenes = [rt.Scene.default(), rt.Scene.generate(rt.KIND_RTIOW, 0, 7), rt.Scene.generate(rt.KIND_CUBE, 700, 3),
+          rt.Scene.generate(rt.KIND_CUBE, 1500, 4), rt.Scene.generate(rt.KIND_CUBE, 33, 5)]
 sizes = [(64, 40), (256, 144), (640, 360), (1280, 720), (1000, 24), (72, 1096)]
 seen = {}
 t0 = time.time()
@@ -24,8 +25,8 @@ with rt.Renderer(64, 64) as r:
     for it in range(iters):
         si = int(rng.integers(len(scenes)))
         w, h = sizes[int(rng.integers(len(sizes)))]
-        frames = int(rng.integers(1, 4))
-        kernel = int(rng.choice([0, 2, 3, 4, 1]))
+        frames = int(rng.choice([1, 2, 3, 33, 64]))  # 32 frames and more: the rows kernel on small scenes
+        kernel = int(rng.choice([0, 2, 3, 4, 1, 5, 6, 7, 8]))
         launch = [(0, 0), (1, 64), (37, 128), (512, 256), (2048, 64), (256, 1024)][int(rng.integers(6))]
         if (r.width, r.height) != (w, h):
             r.resize(w, h)
