@@ -98,11 +98,10 @@ class TileSplit:
             return
         dist = _dist()
         if self.rank == dst:
-            reqs = []
-            for g, (r0, r1) in enumerate(self.bands):
-                if g != dst and r1 > r0:
-                    reqs.append(dist.irecv(image[r0 * 8:r1 * 8], src=g))
-            for q in reqs:
+            # one batch: over RCCL all receives of a frame become one grouped launch instead of one per source
+            ops = [dist.P2POp(dist.irecv, image[r0 * 8:r1 * 8], g)
+                   for g, (r0, r1) in enumerate(self.bands) if g != dst and r1 > r0]
+            for q in dist.batch_isend_irecv(ops) if ops else []:
                 q.wait()
         else:
             r0, r1 = self.rows
