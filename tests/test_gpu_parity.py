@@ -334,17 +334,21 @@ def test_accumulation_continues_without_clear(rt, default_scene):
     assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol)
 
 
-def test_tile_rows_and_frame_stride_split(rt, default_scene):
-    """The two multi-GPU partitions, on one GPU: bands of tile rows, and frames by stride."""
+@pytest.mark.parametrize("scene_name,kernel", [("default", 0), ("default", 7), ("rtiow", 0), ("rtiow", 8)],
+                         ids=["lite", "rows", "matrix", "bvh"])
+def test_tile_rows_and_frame_stride_split(rt, default_scene, rtiow_scene, scene_name, kernel):
+    """The two multi-GPU partitions, on one GPU: bands of tile rows, and frames by stride; for the
+    kernels RT_KERNEL_STREAM picks on the two benchmark scenes, and the two it does not."""
+    default_scene = {"default": default_scene, "rtiow": rtiow_scene}[scene_name]
     w, h = 192, 112  # 14 tile rows
-    full, fcol, fn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=4)
-    top, _, tn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=4, rows=(0, 5))
-    bot, _, bn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=4, rows=(5, 14))
+    full, fcol, fn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=kernel, n_frames=4)
+    top, _, tn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=kernel, n_frames=4, rows=(0, 5))
+    bot, _, bn = _render_gpu(rt, default_scene, w, h, profile=0, kernel=kernel, n_frames=4, rows=(5, 14))
     assert not top[40:].any() and not bot[:40].any()
     assert np.array_equal(_bits(top + bot), _bits(full)) and tn["rays"] + bn["rays"] == fn["rays"]
     # frames {1,3} + frames {2,4}: same samples; only the float summation order differs
-    a, _, an = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=2, frame0=1, stride=2, clear=1)
-    b, _, bn2 = _render_gpu(rt, default_scene, w, h, profile=0, kernel=0, n_frames=2, frame0=2, stride=2, clear=1)
+    a, _, an = _render_gpu(rt, default_scene, w, h, profile=0, kernel=kernel, n_frames=2, frame0=1, stride=2, clear=1)
+    b, _, bn2 = _render_gpu(rt, default_scene, w, h, profile=0, kernel=kernel, n_frames=2, frame0=2, stride=2, clear=1)
     ca, _, _ = _render_cpu(default_scene, w, h, profile=0, n_frames=2, frame0=1, stride=2, clear=1)
     cb, _, _ = _render_cpu(default_scene, w, h, profile=0, n_frames=2, frame0=2, stride=2, clear=1)
     assert np.array_equal(_bits(a), _bits(ca)) and np.array_equal(_bits(b), _bits(cb))
