@@ -369,26 +369,28 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
             hosts[k].copy_(colors[k])
         return hosts[k] if staged else colors[k]
 
-    loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers(accum.data_ptr(), colors[k].data_ptr()), image_of,
-                           dispatch=lambda: r.dispatch_timed(1))
+    # Kernel time: two HIP events on the context's stream around the whole timed region (the launches run back
+    # to back, two frames in flight, so region / launches bounds a launch from above).  Events around every
+    # launch cost ~9 us of a ~45 us frame and, queued behind the previous launch, time its tail too.
+    loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers_next(accum.data_ptr(), colors[k].data_ptr()), image_of)
     for i in range(args.warmup):
         loop.frame(ubos[i])
     loop.finish()
-    r.timed_total()
     r.reset_counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    r.timer_begin()
     for i in range(args.steps):
         loop.frame(ubos[args.warmup + i])
+    kernel_ms = r.timer_end()  # waits for the last launch
     loop.finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms, launches = r.timed_total()
     cnt = r.counters()
     band_rows = (tiles.rows[1] - tiles.rows[0]) * 8
     stats = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["sphere_tests"]), kernel_ms],
@@ -409,14 +411,15 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
                 "workload": f"interactive: default scene (40 traced spheres), {w}x{h}, 1 frame per dispatch, max depth "
                             f"{args.max_depth}, float profile {args.profile}, camera impulse every 40 frames through "
                             "Scene::update (accumulation resets while it moves), uniforms set and dispatch issued per frame",
-                "parallelism": f"bands of 8x8-tile rows over {world} GPU(s); rgba8 bands of frame f gathered to rank 0 "
-                               "while frame f+1 is traced (two colour images)",
+                "parallelism": f"bands of 8x8-tile rows over {world} GPU(s); two frames in flight: frame f+1 is dispatched "
+                               "before the host waits for frame f, whose rgba8 bands are then gathered to rank 0 (two "
+                               "colour images); kernel time = HIP events around the timed region / launches",
                 "launch": f"{info['blocks']} x {info['threads']}",
             },
             "rays_per_second": float(stats[1]) / elapsed,
             "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
             # the slowest rank's kernel time over its launches; tests and pixels of that band
-            "roofline": roofline(args, cnt["sphere_tests"], launches, kernel_ms, (w // 8 * 8) * band_rows,
+            "roofline": roofline(args, cnt["sphere_tests"], args.steps, kernel_ms, (w // 8 * 8) * band_rows,
                                  f"interactive_{args.kernel}_{args.profile}", r.sieve_mode()),
         }
         if args.cpu_seconds > 0 and world == 1:

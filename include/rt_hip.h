@@ -171,6 +171,17 @@ int rt_device_buffers(rt_context* ctx, void** accum_dev, void** color_dev);
    the per-frame rebinding of the colour image to the acquired swap-chain image
    (compute_pipeline.cpp:589-655). */
 int rt_bind_buffers(rt_context* ctx, void* accum_dev, void* color_dev);
+/* The same without waiting for the stream: the images take effect with the NEXT dispatch, a
+   dispatch in flight keeps the images it was launched with.  For two colour images used in turn,
+   as the reference's two frames in flight use their two descriptor sets
+   (src/engine/includes/config.hpp:12, compute_pipeline.cpp:499-513). */
+int rt_bind_buffers_next(rt_context* ctx, void* accum_dev, void* color_dev);
+
+/* Waits until the dispatch issued `back` dispatches ago has finished: 0 = the last one, 1 = the
+   one before it (then the last one may still be running).  back = 1 is the reference's
+   vkWaitForFences on the fence of the frame slot it is about to reuse, two frames in flight
+   (src/engine/engine.cpp:48,132; config.hpp:12).  Returns at once when there is no such dispatch. */
+int rt_sync_dispatch(rt_context* ctx, int back);
 
 /* Re-resolve the colour image from the accumulation image with an explicit
    divisor: colour = unorm8(accum.rgb / divisor)  (shader.comp:129-132), used

@@ -62,6 +62,8 @@ struct rt_context {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};  // recorded after every dispatch, alternating (rt_sync_dispatch)
+    unsigned long long n_dispatch = 0;           // dispatches issued so far
     int width = 0, height = 0;
 
     float4* accum_own = nullptr;
@@ -794,7 +796,9 @@ int rt_create(int device, int width, int height, rt_context** out)
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipStreamCreate failed"));
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done[1], hipEventDisableTiming) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipEventCreate failed"));
     if (hipMalloc(&c->d_work, RT_WORK_BYTES) != hipSuccess || hipMalloc(&c->d_rays, RT_RAY_BYTES) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipMalloc failed"));
@@ -832,6 +836,8 @@ int rt_destroy(rt_context* c)
         }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_done)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -1043,10 +1049,34 @@ int rt_dispatch_frames(rt_context* c, int n_frames)
     rc = launch(c, P, false);
     if (rc != RT_OK) return rc;
     c->paths += (uint64_t)P.total_pixels * (uint64_t)n_frames;
+    HIP_TRY(hipEventRecord(c->ev_done[c->n_dispatch & 1], c->stream));
+    c->n_dispatch++;
     return RT_OK;
 }
 
 int rt_dispatch(rt_context* c) { return rt_dispatch_frames(c, 1); }
+
+int rt_sync_dispatch(rt_context* c, int back)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    if (back < 0 || back > 1) return fail(RT_E_INVALID, "back must be 0 (the last dispatch) or 1 (the one before), got %d", back);
+    RT_ON_DEVICE(c);
+    if (c->n_dispatch <= (unsigned long long)back) return RT_OK;  // no such dispatch yet: nothing to wait for
+    const hipError_t e = hipEventSynchronize(c->ev_done[(c->n_dispatch - 1 - (unsigned)back) & 1]);
+    if (e != hipSuccess) {
+        reset_work(c);
+        return fail(RT_E_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+    }
+    return RT_OK;
+}
+
+int rt_bind_buffers_next(rt_context* c, void* accum_dev, void* color_dev)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    c->accum = accum_dev ? static_cast<float4*>(accum_dev) : c->accum_own;
+    c->color = color_dev ? static_cast<uint32_t*>(color_dev) : c->color_own;
+    return RT_OK;
+}
 
 int rt_dispatch_frames_timed(rt_context* c, int n_frames)
 {

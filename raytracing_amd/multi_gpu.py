@@ -110,15 +110,17 @@ class TileSplit:
 
 
 class InteractiveLoop:
-    """The interactive tile split, pipelined one frame deep: frame f is traced into one of two
-    colour images while the bands of frame f-1 travel to the display rank out of the other, so
-    the exchange of a frame overlaps the tracing of the next one.
+    """The interactive tile split with two frames in flight, as the reference keeps them
+    (src/engine/includes/config.hpp:12): frame f is traced into one of two colour images while the
+    bands of frame f-1 travel to the display rank out of the other, so the exchange of a frame
+    overlaps the tracing of the next one, and frame f is dispatched BEFORE the host waits for frame
+    f-1, so the GPU goes from one frame to the next without waiting for the host.
 
-    `renderer` needs set_uniforms / dispatch / sync; `bind_color(k)` makes colour image k (0 or 1)
-    the one the next dispatch writes and returns only when the previous dispatch has finished
-    (Renderer.bind_buffers does both); `images[k]` is the H x W [x C] tensor of image k that is
-    exchanged (a host copy when the backend cannot move device memory).  `on_frame(f, image)` is
-    called on the display rank with every completed frame, in order.
+    `renderer` needs set_uniforms / dispatch / sync / sync_dispatch; `bind_color(k)` makes colour
+    image k (0 or 1) the one the NEXT dispatch writes, without waiting (Renderer.bind_buffers_next);
+    `image_of(k)` is the H x W [x C] tensor of image k that is exchanged (a host copy when the
+    backend cannot move device memory).  `on_frame(f, image)` is called on the display rank with
+    every completed frame, in order.
     """
 
     def __init__(self, tiles: TileSplit, renderer, bind_color, image_of, on_frame=None, dst: int = 0,
@@ -136,11 +138,12 @@ class InteractiveLoop:
 
     def frame(self, ubo) -> None:
         f = self.count
-        self.bind_color(f % 2)          # returns once frame f-1 is complete in the other image
+        self.bind_color(f % 2)          # frame f-2, the last to write this image, was delivered a call ago
         self.renderer.set_uniforms(ubo)
-        self.dispatch()                 # asynchronous on a GPU
+        self.dispatch()                 # asynchronous on a GPU, queued behind frame f-1
         if f > 0:
-            self._deliver(f - 1)        # ... so frame f-1 is exchanged while frame f is traced
+            self.renderer.sync_dispatch(1)  # frame f-1 is complete; frame f is being traced
+            self._deliver(f - 1)
         self.count = f + 1
 
     def finish(self) -> None:

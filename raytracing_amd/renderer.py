@@ -166,6 +166,14 @@ class Renderer:
     def bind_buffers(self, accum_ptr: int | None, color_ptr: int | None) -> None:
         N.check(N.lib().rt_bind_buffers(self._h, C.c_void_p(accum_ptr), C.c_void_p(color_ptr)))
 
+    def bind_buffers_next(self, accum_ptr: int = 0, color_ptr: int = 0) -> None:
+        """As bind_buffers without waiting: the images take effect with the next dispatch."""
+        N.check(N.lib().rt_bind_buffers_next(self._h, C.c_void_p(accum_ptr), C.c_void_p(color_ptr)))
+
+    def sync_dispatch(self, back: int = 0) -> None:
+        """Wait for the dispatch issued `back` dispatches ago (0: the last one, 1: the one before)."""
+        N.check(N.lib().rt_sync_dispatch(self._h, back))
+
     def trace_crop(self, n_frames: int, x0: int, y0: int, w: int, h: int, want_light: bool = True):
         """Records (n_frames, h, w, max_depth) and per-frame light (n_frames, h, w, 3)."""
         rec = np.empty((n_frames, h, w, self.max_depth), RECORD_DTYPE)

@@ -356,6 +356,52 @@ def test_tile_rows_and_frame_stride_split(rt, default_scene, rtiow_scene, scene_
     np.testing.assert_allclose(a + b, full, rtol=1e-6, atol=1e-6)
 
 
+def test_two_frames_in_flight(rt, default_scene):
+    """rt_bind_buffers_next + rt_sync_dispatch(1): frames traced alternately into two caller-owned
+    colour images, frame f dispatched before frame f-1 is waited for (the reference's two frames in
+    flight), must show what frame-by-frame synchronous rendering shows."""
+    from test_zz_no_alloc import _Hip  # device buffers through the HIP runtime the library itself uses
+
+    hip = _Hip()
+    w, h = 256, 144
+    ubos = []
+    ubo = default_scene.camera.copy()
+    for f in range(6):
+        if f == 3:
+            ubo["camera_position"][0][0] += 0.5  # the camera moves: accumulation restarts
+        ubo["frameCount"][0] = 1 if f in (0, 3) else ubo["frameCount"][0] + 1
+        ubos.append(ubo.copy())
+    with rt.Renderer(w, h) as r:
+        r.upload_spheres(default_scene.spheres)
+        want = []
+        for u in ubos:
+            r.set_uniforms(u)
+            r.dispatch(1)
+            want.append(r.read_color())
+    zero_color, zero_accum = np.zeros((h, w), np.uint32), np.zeros((h, w, 4), np.float32)
+    colors = [hip.upload(zero_color), hip.upload(zero_color)]
+    accum = hip.upload(zero_accum)
+    got = []
+    with rt.Renderer(w, h) as r:
+        r.upload_spheres(default_scene.spheres)
+        r.sync_dispatch(1)  # nothing dispatched yet: returns at once
+        for f, u in enumerate(ubos):
+            r.bind_buffers_next(accum.value, colors[f % 2].value)
+            r.set_uniforms(u)
+            r.dispatch(1)
+            if f > 0:
+                r.sync_dispatch(1)  # frame f-1 is complete, frame f may still be running
+                got.append(hip.download(colors[(f - 1) % 2], zero_color))
+        r.sync_dispatch(0)
+        got.append(hip.download(colors[(len(ubos) - 1) % 2], zero_color))
+        with pytest.raises(rt.RtError):
+            r.sync_dispatch(2)
+        r.bind_buffers(None, None)  # back to the context's own images before the buffers go away
+    hip.free(accum, *colors)
+    for f in range(len(ubos)):
+        assert np.array_equal(got[f].view(np.uint8).reshape(h, w, 4), want[f]), f
+
+
 def test_launch_geometry_does_not_change_bits(rt, rtiow_scene):
     ref = None
     for launch in [(0, 0), (1, 64), (7, 128), (300, 256), (64, 1024), (2048, 64)]:

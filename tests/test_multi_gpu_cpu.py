@@ -36,6 +36,9 @@ class OracleRenderer:
     def sync(self):
         pass
 
+    def sync_dispatch(self, back):
+        pass  # the stand-in's dispatch is synchronous
+
     def set_frame_schedule(self, stride, clear):
         self.stride, self.clear = stride, clear
 
