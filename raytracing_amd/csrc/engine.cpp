@@ -139,6 +139,9 @@ Engine::~Engine()
 
 void Engine::render()
 {
+    // engine.cpp:48: wait for the fence of the frame slot about to be reused -- with two frames in
+    // flight that is the dispatch before the last one; the last one may still be running
+    check(rt_sync_dispatch(m_computePipeline->context(), 1));
     m_computePipeline->render(0, m_currentFrame);
     m_graphicsPipeline->render(0, m_currentFrame);  // engine.cpp:68: after the scene went to the device
     if (m_framebufferResized) {  // engine.cpp:123-127
