@@ -71,7 +71,8 @@ enum {
     RT_KERNEL_BVH = 8          /* STREAM_CULLED's sorted sphere list walked as a hierarchy by every lane on its
                                   own: blocks of 64 slots and their groups of 8 behind axis-aligned boxes, the
                                   spheres of a group behind the sieve (readme.md:38, "BVH implementation");
-                                  same bits.  Same scene sizes as STREAM_CULLED. */
+                                  same bits.  97 to 65536 traced spheres (else STREAM); above 4096 the nodes are
+                                  read from global memory and a level of 512-slot superblocks comes on top. */
 };
 
 /* When the accumulation texel is zeroed. */

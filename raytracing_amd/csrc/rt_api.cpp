@@ -316,6 +316,14 @@ void build_mfma_frags(const std::vector<RtSphereAos>& padded, std::vector<uint32
 // 2^-6 A^2 + 64 kappa^2 |o|^2 that follows from dist_b^2 >= R_b^2 + 65 * 326u |o|^2 = R_b^2 + 21190u
 // |o|^2.  The group test being negative means dist_b^2 > R_b^2 + m_b - err_b - 4u|c_b-o|^2 >= R_b^2 +
 // (2^-9 - 70u)|o|^2 = R_b^2 + 32698u |o|^2.  Hence RT_CULL_MARGIN_O = 2^-9.
+// Entries of the box array beyond the groups: blocks (8 per superblock, at least the RT_BVH_BLOCKS
+// the LDS-resident traversal tests in one go) and superblocks (tested 4 at a time).
+int block_boxes(int n_pad)
+{
+    return std::max(RT_BVH_BLOCKS, ((n_pad + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK + 7) / 8 * 8);
+}
+int super_boxes(int n_pad) { return std::max(4, ((n_pad + RT_BVH_SUPER - 1) / RT_BVH_SUPER + 3) / 4 * 4); }
+
 struct CulledScene {
     std::vector<float> geom;    // 4 floats per slot, pair-packed
     std::vector<float> radius;  // per slot
@@ -351,15 +359,15 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
             rest.push_back(i);
     }
     // The rest: recursive median splits along the longest axis of the centres, cut at the slot
-    // boundaries of blocks (RT_BVH_BLOCK slots) first and of groups (RT_CULL_GROUP) inside them, so
-    // that every block and every group is a compact cell of a k-d partition.  (Runs of a Morton
+    // boundaries of superblocks (RT_BVH_SUPER slots) first, then of blocks (RT_BVH_BLOCK) and of groups
+    // (RT_CULL_GROUP) inside them, so that each of them is a compact cell of a k-d partition.  (Runs of a Morton
     // curve, the first version, are not: 64 consecutive points of a 22 x 22 grid came out as
     // rectangles up to 22 x 8 that overlapped one another.)
     {
         const int base = (int)keyed.size();  // slot of rest[0]
         auto coord = [&](int i, int axis) { return axis == 0 ? src[i].cx : axis == 1 ? src[i].cy : src[i].cz; };
         struct Range { int lo, hi, unit; };
-        std::vector<Range> todo{{0, (int)rest.size(), RT_BVH_BLOCK}};
+        std::vector<Range> todo{{0, (int)rest.size(), RT_BVH_SUPER}};
         while (!todo.empty()) {
             const Range r = todo.back();
             todo.pop_back();
@@ -368,7 +376,7 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
             const int first = ((base + r.lo) / r.unit + 1) * r.unit - base;
             const int nb = first < r.hi ? (r.hi - 1 - first) / r.unit + 1 : 0;
             if (nb == 0) {
-                if (r.unit > RT_CULL_GROUP) todo.push_back({r.lo, r.hi, RT_CULL_GROUP});
+                if (r.unit > RT_CULL_GROUP) todo.push_back({r.lo, r.hi, r.unit == RT_BVH_SUPER ? RT_BVH_BLOCK : RT_CULL_GROUP});
                 else std::sort(rest.begin() + r.lo, rest.begin() + r.hi);  // inside a group: index order
                 continue;
             }
@@ -450,18 +458,20 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
     }
 
     // Boxes for the per-lane traversal (RT_KERNEL_BVH; trace_bvh in rt_kernels.hip has the test and
-    // why it is conservative): entries 0 .. nbounds-1 the groups of RT_CULL_GROUP slots, entries
-    // nbounds .. nbounds+RT_BVH_BLOCKS-1 the blocks of RT_BVH_BLOCK slots.  The box of a node holds
+    // why it is conservative): entries 0 .. nbounds-1 the groups of RT_CULL_GROUP slots, then
+    // block_boxes(n_pad) blocks of RT_BVH_BLOCK slots, then super_boxes(n_pad) superblocks of RT_BVH_SUPER.  The box of a node holds
     // every member sphere with its radius enlarged by RT_BOX_PAD (|c| + r); the kernel adds
     // RT_BOX_PAD |o| for its ray.  Stored as centre and half-width, pair-packed per axis: entries
     // (2k, 2k+1) = {cx0, cx1, hx0, hx1}, {cy0, cy1, hy0, hy1}, {cz0, cz1, hz0, hz1}.  A node with a
     // non-finite member gets half-width +inf (always entered), a node without spheres -inf (never).
-    const int nboxes = nbounds + RT_BVH_BLOCKS;
+    const int nblocks = block_boxes(n_pad), nsupers = super_boxes(n_pad);
+    const int nboxes = nbounds + nblocks + nsupers;
     out->boxes.assign((size_t)nboxes * 6, 0.f);
     for (int g = 0; g < nboxes; g++) {
-        const bool block = g >= nbounds;
-        const int first = block ? (g - nbounds) * RT_BVH_BLOCK : g * RT_CULL_GROUP;
-        const int end = std::min(count, first + (block ? RT_BVH_BLOCK : RT_CULL_GROUP));
+        const int level = g < nbounds ? 0 : g < nbounds + nblocks ? 1 : 2;
+        const int size = level == 0 ? RT_CULL_GROUP : level == 1 ? RT_BVH_BLOCK : RT_BVH_SUPER;
+        const int first = (g - (level == 0 ? 0 : level == 1 ? nbounds : nbounds + nblocks)) * size;
+        const int end = std::min(count, first + size);
         float ctr[3] = {0.f, 0.f, 0.f}, half[3] = {-inf, -inf, -inf};
         if (first < count) {
             bool ok = true;
@@ -577,7 +587,7 @@ int ensure_culled(rt_context* c, int count, int n_pad)
         HIP_TRY(hipMalloc(&c->d_cgeom, (size_t)n_pad * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->d_cradius, (size_t)n_pad * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_bounds, nbounds * sizeof(float4)));
-        HIP_TRY(hipMalloc(&c->d_boxes, (nbounds + RT_BVH_BLOCKS) * 6 * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_boxes, (nbounds + block_boxes(n_pad) + super_boxes(n_pad)) * 6 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_perm, (size_t)n_pad * sizeof(int)));
         c->cull_cap = n_pad;
     }
@@ -594,10 +604,10 @@ int ensure_culled(rt_context* c, int count, int n_pad)
 // and perm.  False when the scene does not qualify: empty, too large to stage in LDS, or (unless
 // `force`, which the audit uses) so small that the group test costs more than it saves -- measured,
 // the 40-sphere default scene runs 12 % slower culled.
-int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false)
+int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false, int max_spheres = RT_MAX_LDS_SPHERES)
 {
     *on = false;
-    if (P->n_pad == 0 || P->n_pad > RT_MAX_LDS_SPHERES) return RT_OK;
+    if (P->n_pad == 0 || P->n_pad > max_spheres) return RT_OK;
     if (!force && P->n_pad < 128) return RT_OK;
     int rc = ensure_culled(c, P->sphere_count, P->n_pad);
     if (rc != RT_OK) return rc;
@@ -606,6 +616,7 @@ int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false)
     P->bounds = c->d_bounds;
     P->boxes = c->d_boxes;
     P->n_bounds = (P->n_pad / RT_CULL_GROUP + 63) / 64 * 64;
+    P->n_block_boxes = block_boxes(P->n_pad);
     P->perm = c->d_perm;
     *on = true;
     return RT_OK;
@@ -736,9 +747,16 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     if (mfma) mode = far ? 5 : 3;
     if (c->kernel == RT_KERNEL_STREAM_CULLED || c->kernel == RT_KERNEL_BVH) {
         bool on = false;
-        const int rc = use_culled(c, &P, &on);
+        const bool bvh = c->kernel == RT_KERNEL_BVH;
+        const int rc = use_culled(c, &P, &on, false, bvh ? RT_BVH_FAR_MAX_SPHERES : RT_MAX_LDS_SPHERES);
         if (rc != RT_OK) return rc;
-        if (on) mode = c->kernel == RT_KERNEL_BVH && P.n_pad <= RT_BVH_BLOCK * RT_BVH_BLOCKS ? 4 : 2;
+        // per-lane traversal: out of LDS while the scene fits there, out of global memory beyond
+        static const int far_from = env_int("RT_DEBUG_BVH_FAR_FROM", RT_BVH_BLOCK * RT_BVH_BLOCKS + 1);  // development knob
+        if (on) mode = !bvh ? 2 : P.n_lds != 0 && P.n_pad < far_from ? 4 : 6;
+        if (mode == 6 && P.n_lds != 0) {  // nothing staged: geometry for workgroup size and LDS as for a scene beyond LDS
+            P.n_lds = 0;
+            stream_geometry(c, P, &blocks, &threads);
+        }
         if (mode == 4 && rt_stream_lds_bytes(P.n_lds, threads, false, P.n_bounds * 3 / 2) > kLdsPerCu)
             return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     }
@@ -756,7 +774,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     }
     c->last_blocks = blocks;
     c->last_threads = threads;
-    c->last_mode = mode == 4 ? 6 : mode == 5 ? 3 : mode;
+    c->last_mode = mode == 4 || mode == 6 ? 6 : mode == 5 ? 3 : mode;
     return RT_OK;
 }
 
@@ -1417,7 +1435,7 @@ int rt_debug_cull_audit(rt_context* c, const float* rays, int n_rays, uint64_t o
     int rc = make_params(c, 1, &P);
     if (rc != RT_OK) return rc;
     bool on = false;
-    rc = use_culled(c, &P, &on, true);
+    rc = use_culled(c, &P, &on, true, RT_BVH_FAR_MAX_SPHERES);
     if (rc != RT_OK) return rc;
     if (!on) return fail(RT_E_INVALID, "the culled kernel does not apply to this scene (%d spheres)", P.sphere_count);
     float* d_rays = nullptr;

@@ -1676,6 +1676,131 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
 #endif
 }
 
+// The same walk for scenes too large for LDS (MODE 6; up to RT_BVH_FAR_MAX_SPHERES spheres): one level
+// more -- superblocks of RT_BVH_SUPER = 512 slots, whose boxes the whole wave tests from the scalar
+// cache, a 128-bit mask per lane -- and every node read from global memory (the sorted geometry and
+// the boxes stay resident in L2) at the lane's own address.
+template <bool FUSED>
+__device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive, const RtParams& P, float& best, int& idx)
+{
+    const SieveRay sr = sieve_ray(p, a, alive);
+    const BoxRay br = box_ray(p, a);
+    const v4f* geom = reinterpret_cast<const v4f*>(P.geom);
+    const float* gf = reinterpret_cast<const float*>(P.geom);
+    const v4f* boxes = reinterpret_cast<const v4f*>(P.boxes);
+    const v4f* block_boxes = boxes + (P.n_bounds >> 1) * 3;
+    // group 0, the largest spheres, first (see trace_bvh)
+    {
+        ConstGeomPtr g0 = (ConstGeomPtr)(const void*)(P.geom);
+        const v2f none2 = {__builtin_inff(), __builtin_inff()};
+        uint32_t rej = 0;
+#pragma unroll
+        for (int k = 0; k < RT_CULL_GROUP / 2; k++) bvh_pair(rej, g0[2 * k], g0[2 * k + 1], sr, none2);
+        uint32_t cand = (~rej) << (32 - RT_CULL_GROUP);
+        while (__ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int i = __clz(cand);
+                cand &= ~(0x80000000u >> i);
+                bool far_root = false;
+                if (P.materials != nullptr) far_root = P.materials[P.perm[i]].x == 3.0f;  // wave-uniform branch
+                const float* f = gf + (i >> 1) * 8 + (i & 1);
+                test_sphere<FUSED>(p, a, f[0], f[2], f[4], P.radius[i], i, best, idx, far_root, P.perm);
+            }
+        }
+    }
+    // superblock boxes, 4 at a time from the scalar cache: bit (31 - n) of sm[w] = superblock 32 w + n
+    const int nsb = (P.n_pad + RT_BVH_SUPER - 1) / RT_BVH_SUPER;
+    const int n4 = (nsb + 3) >> 2;
+    ConstGeomPtr sb = (ConstGeomPtr)(const void*)(P.boxes) + ((P.n_bounds + P.n_block_boxes) >> 1) * 3;
+    const float reach0 = bvh_reach(best, a);
+    uint32_t sm[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int quads = min(8, n4 - 8 * w);  // wave-uniform
+        if (quads <= 0) continue;
+        uint32_t rej = 0u;
+#pragma unroll 1
+        for (int n = 8 * w; n < 8 * w + quads; n++) {
+            bvh_box_pair(rej, sb[6 * n], sb[6 * n + 1], sb[6 * n + 2], br, reach0);
+            bvh_box_pair(rej, sb[6 * n + 3], sb[6 * n + 4], sb[6 * n + 5], br, reach0);
+        }
+        sm[w] = alive ? ~rej << (32 - 4 * quads) : 0u;
+    }
+    uint32_t bm = 0, gm = 0;  // blocks of the open superblock / groups of the open block still to be visited
+    int sup = 0, blk = 0;
+    auto test_boxes = [&](const v4f* g) -> uint32_t {  // 8 boxes = 4 pairs = 12 float4 at the lane's own address
+        v4f e[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) e[k] = g[k];
+        const float reach = bvh_reach(best, a);
+        uint32_t rej = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) bvh_box_pair(rej, e[3 * k], e[3 * k + 1], e[3 * k + 2], br, reach);
+        return (~rej) << 24;
+    };
+    for (;;) {
+        // ---- lanes with nothing open below open their next superblock
+        const bool open_sup = gm == 0u && bm == 0u && (sm[0] | sm[1] | sm[2] | sm[3]) != 0u;
+        if (__ballot(open_sup) != 0ull) {
+            if (open_sup) {
+                int w = sm[0] ? 0 : sm[1] ? 1 : sm[2] ? 2 : 3;
+                uint32_t word = w == 0 ? sm[0] : w == 1 ? sm[1] : w == 2 ? sm[2] : sm[3];
+                const int k = __clz(word);
+                word &= ~(0x80000000u >> k);
+                sm[0] = w == 0 ? word : sm[0]; sm[1] = w == 1 ? word : sm[1];
+                sm[2] = w == 2 ? word : sm[2]; sm[3] = w == 3 ? word : sm[3];
+                sup = 32 * w + k;
+                bm = test_boxes(block_boxes + sup * 12);
+            }
+        }
+        // ---- lanes without an open group open their next block
+        const bool open_blk = gm == 0u && bm != 0u;
+        if (__ballot(open_blk) != 0ull) {
+            if (open_blk) {
+                const int k = __clz(bm);
+                bm &= ~(0x80000000u >> k);
+                blk = sup * (RT_BVH_SUPER / RT_BVH_BLOCK) + k;
+                gm = test_boxes(boxes + blk * 12);
+                if (blk == 0) gm &= 0x7fffffffu;  // group 0 has been dealt with
+            }
+        }
+        // ---- lanes with an open group sieve its next group of spheres
+        const bool leaf = gm != 0u;
+        if (__ballot(leaf) == 0ull) {
+            if (__ballot((bm | sm[0] | sm[1] | sm[2] | sm[3]) != 0u) == 0ull) break;
+            continue;
+        }
+        int grp = 0;
+        uint32_t cand = 0u;
+        if (leaf) {
+            const int k = __clz(gm);
+            gm &= ~(0x80000000u >> k);
+            grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + k;
+            const v4f* g = geom + grp * RT_CULL_GROUP;
+            v4f e[RT_CULL_GROUP];
+#pragma unroll
+            for (int k2 = 0; k2 < RT_CULL_GROUP; k2++) e[k2] = g[k2];
+            const float reach = bvh_reach(best, a);
+            const v2f bh = {reach, reach};
+            uint32_t rej = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < RT_CULL_GROUP / 2; k2++) bvh_pair(rej, e[2 * k2], e[2 * k2 + 1], sr, bh);
+            cand = (~rej) << (32 - RT_CULL_GROUP);
+        }
+        while (__ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int b = __clz(cand);
+                cand &= ~(0x80000000u >> b);
+                const int i = grp * RT_CULL_GROUP + b;
+                bool far_root = false;
+                if (P.materials != nullptr) far_root = P.materials[P.perm[i]].x == 3.0f;  // wave-uniform branch
+                const float* f = gf + (i >> 1) * 8 + (i & 1);
+                test_sphere<FUSED>(p, a, f[0], f[2], f[4], P.radius[i], i, best, idx, far_root, P.perm);
+            }
+        }
+    }
+}
+
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= RT_STREAM_MAX_THREADS); dynamic LDS =
 // rt_stream_lds_bytes(): n_pad*16 B sieve geometry + n_pad*4 B radii + per mode the matrix-core
 // operands or the group bounds + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
@@ -1687,7 +1812,7 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
 // first sieves the 64 bounding spheres of their groups of 8, ORs the result over its lanes, and
 // skips the groups no lane can touch.  3 = the sieve on the matrix cores.  4 = per-lane traversal
 // of the sorted list (trace_bvh).  5 = as 3 for scenes of more than RT_MAX_MFMA_SPHERES spheres: the
-// sphere-side operands stay in global memory.
+// sphere-side operands stay in global memory.  6 = as 4 for scenes too large for LDS (trace_bvh_far).
 template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
 {
@@ -1696,7 +1821,8 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     constexpr bool MFMA = MODE == 3 || MODE == 5;
     constexpr bool FAR_FRAGS = MODE == 5;  // matrix-core sieve with its sphere-side operands left in global memory
     constexpr bool BVH = MODE == 4;
-    constexpr bool SORTED = CULL || BVH;  // slots of the sorted list: P.perm maps them to the shader's indices
+    constexpr bool BVH_FAR = MODE == 6;  // per-lane traversal out of global memory (nothing staged: P.n_lds == 0)
+    constexpr bool SORTED = CULL || BVH || BVH_FAR;  // slots of the sorted list: P.perm maps them to the shader's indices
     extern __shared__ float4 smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1857,6 +1983,9 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         int idx = -1;
         if constexpr (BVH) {
             trace_bvh<FUSED>(p, a, alive, P, smem, radius, reinterpret_cast<const float4*>(frags), best, idx);
+            RT_MARK(t_walk)
+        } else if constexpr (BVH_FAR) {
+            trace_bvh_far<FUSED>(p, a, alive, P, best, idx);
             RT_MARK(t_walk)
         } else {
             SieveRay sr;
@@ -2094,7 +2223,7 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
 // the literal discriminant of the group's spheres under both float profiles.
 // out[0]: (ray, sphere) pairs culled with a non-negative discriminant (must stay 0);
 // out[1]: (ray, group) pairs culled; out[2]: (ray, group) pairs tested; out[3], out[4]: (ray, node)
-// pairs the per-lane traversal's box test drops / examines, over groups and blocks (a node dropped
+// pairs the per-lane traversal's box test drops / examines, over groups, blocks and superblocks (a node dropped
 // although a member has a literal hit counts into out[0]); out[5]: spheres with a literal hit that
 // the traversal's distance test would prune, itself or by the box of its group or block, when the
 // nearest hit so far is that very hit (must stay 0); out[6]: literal hits so examined.
@@ -2145,12 +2274,14 @@ __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, co
         bvh_box_pair(m, box[(entry >> 1) * 3], box[(entry >> 1) * 3 + 1], box[(entry >> 1) * 3 + 2], br, bh);
         return ((m >> (1 - (entry & 1))) & 1u) != 0u;
     };
-    for (int node = 0; node < ngroups + nblk && live; node++) {
-        const bool block = node >= ngroups;
-        const int first = block ? (node - ngroups) * RT_BVH_BLOCK : node * RT_CULL_GROUP;
-        const int size = block ? RT_BVH_BLOCK : RT_CULL_GROUP;
+    const int nsup = (P.n_pad + RT_BVH_SUPER - 1) / RT_BVH_SUPER;
+    for (int node = 0; node < ngroups + nblk + nsup && live; node++) {
+        const int level = node < ngroups ? 0 : node < ngroups + nblk ? 1 : 2;
+        const int at = node - (level == 0 ? 0 : level == 1 ? ngroups : ngroups + nblk);
+        const int size = level == 0 ? RT_CULL_GROUP : level == 1 ? RT_BVH_BLOCK : RT_BVH_SUPER;
+        const int first = at * size;
         if (first >= P.sphere_count) continue;
-        const int entry = block ? P.n_bounds + (node - ngroups) : node;
+        const int entry = level == 0 ? at : level == 1 ? P.n_bounds + at : P.n_bounds + P.n_block_boxes + at;
         btested++;
         const bool rej_s = box_rejects(entry, br_s, __builtin_inff()), rej_f = box_rejects(entry, br_f, __builtin_inff());
         if (!rej_s && !rej_f) continue;
@@ -2188,6 +2319,7 @@ __global__ void __launch_bounds__(256) rt_cull_audit_kernel(const RtParams P, co
             bool rejected = ((m >> (1 - (k & 1))) & 1u) != 0u;
             rejected = rejected || box_rejects(k / RT_CULL_GROUP, prof ? br_f : br_s, reach);
             rejected = rejected || box_rejects(P.n_bounds + k / RT_BVH_BLOCK, prof ? br_f : br_s, reach);
+            rejected = rejected || box_rejects(P.n_bounds + P.n_block_boxes + k / RT_BVH_SUPER, prof ? br_f : br_s, reach);
             if (rejected) pruned++;
         }
     }
@@ -2264,7 +2396,8 @@ size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4)
 
 // mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
 // 3 = sieve on the matrix cores (P.frags set, P.n_lds != 0), 4 = per-lane traversal (P.boxes/P.perm/P.n_bounds
-// set, P.n_lds != 0), 5 = as 3 with the operands read from global memory (P.frags set, P.n_lds != 0)
+// set, P.n_lds != 0), 5 = as 3 with the operands read from global memory (P.frags set, P.n_lds != 0),
+// 6 = per-lane traversal out of global memory (P.boxes/P.perm/P.n_bounds/P.n_block_boxes set)
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st)
 {
@@ -2282,6 +2415,13 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
                          : launch_stream<false, true, 2>(P, blocks, threads, lds, st);
         return fused ? launch_stream<true, false, 2>(P, blocks, threads, lds, st)
                      : launch_stream<false, false, 2>(P, blocks, threads, lds, st);
+    }
+    if (mode == 6) {
+        if (record)
+            return fused ? launch_stream<true, true, 6>(P, blocks, threads, lds, st)
+                         : launch_stream<false, true, 6>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, false, 6>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 6>(P, blocks, threads, lds, st);
     }
     if (mode == 5) {
         if (record)

@@ -59,6 +59,10 @@ constexpr float RT_CULL_MARGIN_O = 0.001953125f;
 constexpr int RT_BVH_BLOCK = 64;
 constexpr int RT_BVH_BLOCKS = 64;
 constexpr float RT_BOX_PAD = 0.002f;
+// Scenes too large for LDS are walked out of global memory with one level more: superblocks of
+// RT_BVH_SUPER slots (8 blocks), at most 128 of them (a 128-bit mask per lane).
+constexpr int RT_BVH_SUPER = 512;
+constexpr int RT_BVH_FAR_MAX_SPHERES = 128 * RT_BVH_SUPER;
 // Pixels a wave takes from a work queue at a time (one 8x8 tile).
 #ifndef RT_SPAN_PIXELS
 #define RT_SPAN_PIXELS 64
@@ -114,8 +118,10 @@ struct RtParams {
     const float4* bounds;        // pair-packed like geom: bounding sphere of every group of 8 slots,
                                  // padded to a multiple of 64 groups with never-touched entries
     int n_bounds;                // group entries in `bounds` (a multiple of 64)
-    const float4* boxes;         // per-lane traversal: boxes of the n_bounds groups, then of RT_BVH_BLOCKS blocks of
-                                 // 64 slots; centre and half-width pair-packed per axis, 3 float4 per pair of entries
+    const float4* boxes;         // per-lane traversal: boxes of the n_bounds groups, then of n_block_boxes blocks of
+                                 // 64 slots, then of the superblocks of 512 slots; centre and half-width
+                                 // pair-packed per axis, 3 float4 per pair of entries
+    int n_block_boxes;           // block entries in `boxes` (a multiple of 8, at least RT_BVH_BLOCKS)
     const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8

@@ -24,7 +24,7 @@ def rt():
     return raytracing_amd
 
 
-@pytest.mark.parametrize("scene_name", ["default", "rtiow", "cube1000", "cube4096"])
+@pytest.mark.parametrize("scene_name", ["default", "rtiow", "cube1000", "cube4096", "cube9000"])
 def test_group_test_never_culls_a_literal_candidate(rt, default_scene, rtiow_scene, scene_name):
     """Audit of the group test alone: over camera-like, random and limb-grazing rays, no sphere with
     a non-negative literal discriminant (either profile) may sit in a culled group; and the test
@@ -82,11 +82,20 @@ def test_culled_sphere_counts(rt, count, kernel):
 
 
 @BOTH
-def test_culled_falls_back_above_4096_spheres(rt, kernel):
-    scene = rt.Scene.generate(rt.KIND_CUBE, 5000, 21)
-    acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=1, kernel=kernel, n_frames=1, depth=4)
-    cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=1, n_frames=1, depth=4)
-    assert np.array_equal(_bits(acc), _bits(cacc)) and cnt["rays"] == crays
+@pytest.mark.parametrize("count", [5000, 4097, 20000])
+def test_above_4096_spheres(rt, kernel, count):
+    """Beyond what LDS holds the culled kernel falls back to the brute-force kernel, and the per-lane
+    traversal walks out of global memory with a level of 512-slot superblocks on top."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, count, 21)
+    acc, col, cnt = _render_gpu(rt, scene, 96, 64, profile=1, kernel=kernel, n_frames=2, depth=4)
+    cacc, ccol, crays = _render_cpu(scene, 96, 64, profile=1, n_frames=2, depth=4)
+    assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and cnt["rays"] == crays
+    with rt.Renderer(96, 64) as r:
+        r.set_kernel(kernel)
+        r.set_scene(scene, frame_count=1)
+        r.dispatch(1)
+        r.sync()
+        assert r.sieve_mode() == (6 if kernel == BVH else 1)
 
 
 @BOTH

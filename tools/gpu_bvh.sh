@@ -9,6 +9,11 @@ if [ -f variants/libpasses.so ]; then
     RT_AMD_LIB=variants/libpasses.so timeout -k 10 120 python3 tools/one_dispatch.py $wl 2>&1 | grep -v "^passes" | tee -a "$out/s.txt"
   done
 fi
+for k in 0 8; do
+  for wl in "cube16384 3840 2160 2 50 $k 2" "cube65536 3840 2160 1 50 $k 1"; do
+    timeout -k 10 200 python3 tools/one_dispatch.py $wl 2>&1 | tee -a "$out/k.txt"
+  done
+done
 for k in 0 4 8; do
   for wl in "rtiow 3840 2160 8 50 $k 3" "cube4096 3840 2160 2 50 $k 3" "cube1000 3840 2160 4 50 $k 3"; do
     timeout -k 10 120 python3 tools/one_dispatch.py $wl 2>&1 | tee -a "$out/k.txt"
