@@ -284,6 +284,30 @@ def test_more_spheres_than_fit_in_lds(rt):
     assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(_bits(light), _bits(clight))
 
 
+@pytest.mark.parametrize("count", [4097, 6000, 12000])
+def test_brute_force_above_4096_spheres(rt, count):
+    """Scenes too large for LDS: the matrix-core sieve streams its operands and the walk reads the
+    sphere records from global memory; image, colour, ray count and per-bounce records vs the oracle."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, count, 9)
+    w, h = 96, 64
+    for profile in (0, 1):
+        acc, col, cnt = _render_gpu(rt, scene, w, h, profile=profile, kernel=0, n_frames=2, depth=6)
+        cacc, ccol, crays = _render_cpu(scene, w, h, profile=profile, n_frames=2, depth=6)
+        assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and cnt["rays"] == crays
+    ubo = scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    with rt.Renderer(w, h) as r:
+        r.upload_spheres(scene.spheres)
+        r.set_uniforms(ubo)
+        r.dispatch(1)
+        r.sync()
+        assert r.sieve_mode() == 3  # the matrix cores
+        rec, light = r.trace_crop(1, 40, 24, 16, 8)
+    crec, clight = O.trace_crop(ubo, scene.spheres, w, h, 40, 24, 16, 8)
+    assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(rec["hash"], crec["hash"])
+    assert np.array_equal(_bits(light), _bits(clight))
+
+
 def test_stress_4096_spheres_crop(rt):
     """Config 'stress4096' (depth 50): records on a crop vs the oracle, both kernels agree on an image."""
     scene = rt.Scene.generate(rt.KIND_CUBE, 4096, 3)
