@@ -15,7 +15,8 @@ import raytracing_amd as rt  # noqa: E402
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 scenes = [rt.Scene.default(), rt.Scene.generate(rt.KIND_RTIOW, 0, 7), rt.Scene.generate(rt.KIND_CUBE, 700, 3),
-          rt.Scene.generate(rt.KIND_CUBE, 1500, 4), rt.Scene.generate(rt.KIND_CUBE, 33, 5)]
+          rt.Scene.generate(rt.KIND_CUBE, 1500, 4), rt.Scene.generate(rt.KIND_CUBE, 33, 5),
+          rt.Scene.generate(rt.KIND_CUBE, 4500, 6)]
 sizes = [(64, 40), (256, 144), (640, 360), (1280, 720), (1000, 24), (72, 1096)]
 seen = {}
 t0 = time.time()
