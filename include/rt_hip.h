@@ -47,9 +47,10 @@ enum {
 
 /* Which kernel runs a dispatch.  All give bit-identical images. */
 enum {
-    RT_KERNEL_STREAM = 0, /* persistent waves; a lane whose path ends takes the next pixel;
-                             picks the sieve (matrix cores or one of the two vector-ALU
-                             variants below) by sphere count                                   */
+    RT_KERNEL_STREAM = 0, /* the default: brute force, the kernel chosen by sphere count -- up to 64
+                             traced spheres LITE or ROWS, from 65 to 65536 persistent waves (a lane
+                             whose path ends takes the next pixel) with the sieve on the matrix
+                             cores, beyond that with the vector-ALU sieve                        */
     RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
     RT_KERNEL_STREAM_SGPR = 2, /* STREAM, sieve geometry read through the scalar cache (SGPRs) */
     RT_KERNEL_STREAM_LDS = 3,  /* STREAM, sieve geometry read from the LDS copy                */
@@ -61,13 +62,14 @@ enum {
     RT_KERNEL_STREAM_MFMA = 5, /* STREAM with the sieve's two dot products (rays x spheres, K = 4) evaluated by the
                                   matrix cores on exact three-term bf16 splits of the f32 operands; the vector
                                   ALU keeps 2 instructions per test.  RT_KERNEL_STREAM picks it by itself from
-                                  33 to 1024 traced spheres; this value forces it from 1 sphere on. */
+                                  65 to 65536 traced spheres; this value forces it from 1 sphere on. */
     RT_KERNEL_LITE = 6,        /* at most 64 traced spheres (else STREAM): one wave per 8x8 tile as in TILE, no work
                                   queues, with STREAM's sieve and candidate walk and every lane running its
-                                  pixel's frames back to back. */
+                                  pixel's frames back to back; RT_KERNEL_STREAM picks it for such scenes unless
+                                  ROWS fits the dispatch better. */
     RT_KERNEL_ROWS = 7,        /* at most 64 traced spheres (else STREAM): persistent waves whose lanes take work
                                   path by path, (pixel, frame), and add each pixel's frames in order through
-                                  LDS; RT_KERNEL_STREAM picks it for such scenes. */
+                                  LDS; RT_KERNEL_STREAM picks it for 32 and more frames of a small image. */
     RT_KERNEL_BVH = 8          /* STREAM_CULLED's sorted sphere list walked as a hierarchy by every lane on its
                                   own: blocks of 64 slots and their groups of 8 behind axis-aligned boxes, the
                                   spheres of a group behind the sieve (readme.md:38, "BVH implementation");
