@@ -87,6 +87,12 @@ struct rt_context {
     float4* d_cgeom = nullptr;    // pair-packed sieve geometry of the sorted list
     float* d_cradius = nullptr;   // radii of the sorted list
     float4* d_bounds = nullptr;   // pair-packed bounding spheres of the groups of RT_CULL_GROUP slots
+    // lite kernel: rays per tile of its last dispatch, and the tile order made from them for the next one
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    unsigned tile_cap = 0;       // tiles both arrays have room for
+    unsigned cost_tiles = 0;     // tiles d_tile_cost describes (0: nothing yet), for the region below
+    int cost_region[4] = {0, 0, 0, 0};  // tile_col0, tile_cols, tile_row0, tile_rows of that dispatch
     float4* d_boxes = nullptr;    // per-lane traversal: boxes of the groups, then of the blocks (3 float4 per pair)
     int* d_perm = nullptr;        // sorted slot -> index in d_spheres
     int cull_cap = 0;             // slots allocated
@@ -716,7 +722,37 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             c->fail_next_launch = false;
             e = hipErrorLaunchFailure;
         } else {
+            // Longest tiles first, from the costs the previous dispatch of the same region left behind
+            // (rt_tile_order_kernel; 10 us for a 1080p image, 70 us for 4K).  Measured on the default scene:
+            // 1920x1080 x 64 frames 2.98 -> 2.47 ms, x 8 frames 394 -> 385 us; 3840x2160 x 8 frames 1.27 -> 1.37 ms.
+            static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 16);  // development knob; < 0: never
+            const unsigned ntiles = P.total_pixels / 64u;
+            const int region[4] = {P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows};
+            if (lpt_min_frames >= 0 && ntiles > c->tile_cap) {
+                if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+                if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+                c->d_tile_cost = c->d_tile_order = nullptr;
+                c->tile_cap = c->cost_tiles = 0;
+                if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 4) == hipSuccess &&
+                    hipMalloc(&c->d_tile_order, (size_t)ntiles * 4) == hipSuccess) {
+                    c->tile_cap = ntiles;
+                } else {  // no room: the dispatch runs in image order
+                    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+                    c->d_tile_cost = c->d_tile_order = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+            const bool known = c->cost_tiles == ntiles && memcmp(region, c->cost_region, sizeof region) == 0;
+            P.tile_cost = lpt_min_frames >= 0 && c->tile_cap >= ntiles ? c->d_tile_cost : nullptr;
+            P.tile_order = nullptr;
+            if (P.tile_cost && known && P.n_frames >= lpt_min_frames &&
+                rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, c->stream) == hipSuccess)
+                P.tile_order = c->d_tile_order;
             e = rt_launch_lite(P, fused, threads, c->stream);
+            if (e == hipSuccess && P.tile_cost) {
+                c->cost_tiles = ntiles;
+                memcpy(c->cost_region, region, sizeof region);
+            }
         }
         if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
         c->last_mode = 4;
@@ -844,6 +880,8 @@ int rt_destroy(rt_context* c)
     if (c->d_cradius) (void)hipFree(c->d_cradius);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_boxes) (void)hipFree(c->d_boxes);
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);

@@ -388,7 +388,7 @@ __device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
 // the sphere count of this dispatch (word 2), into one of RT_RAY_SLOTS slots a cache line apart
 // (the host adds them up): the waves of a launch finish together, and on a single address their
 // additions would complete one after the other.
-__device__ __forceinline__ void add_rays(const RtParams& P, unsigned nrays, unsigned slot)
+__device__ __forceinline__ unsigned long long add_rays(const RtParams& P, unsigned nrays, unsigned slot)
 {
     unsigned long long v = nrays;
 #pragma unroll
@@ -398,6 +398,7 @@ __device__ __forceinline__ void add_rays(const RtParams& P, unsigned nrays, unsi
     if ((lane == 0 || lane == 2) && v != 0)
         atomicAdd(P.rays + (slot % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + lane,
                   lane == 0 ? v : v * (unsigned long long)P.sphere_count);
+    return v;  // the wave's rays
 }
 
 // ---------------------------------------------------------------- tile kernel
@@ -639,8 +640,10 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         smem[i] = reinterpret_cast<const float4*>(P.spheres)[i];
     for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
     __syncthreads();
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
+    // heaviest tiles first, when the previous dispatch left their costs (rt_tile_order_kernel)
+    const uint32_t tile = P.tile_order ? P.tile_order[slot] : slot;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
     const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
@@ -717,7 +720,42 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         }
     }
     store_pixel(P, px, py, acc);
-    add_rays(P, nrays, tile);
+    const unsigned long long wave_rays = add_rays(P, nrays, tile);
+    if (P.tile_cost != nullptr && lane == 0) P.tile_cost[tile] = (uint32_t)min(wave_rays, 0xffffffffull);
+}
+
+// Order of the tiles for the NEXT dispatch of rt_lite_kernel: descending cost (rays of the tile in
+// the dispatch before), by a counting sort over 256 cost classes.  A tile with all its frames is
+// the unit the hardware dispatcher hands out, between 64 and several hundred passes long; handed
+// out in image order, the heaviest tiles start whenever their turn comes and the dispatch ends
+// waiting for them (measured: 25 % of the vector ALU idle at 1080p x 64 frames).  Longest first,
+// they start at once and the light ones fill in behind.  The order only says who goes first: the
+// bits of the image cannot depend on it.  One workgroup of 1024 threads; n = number of tiles.
+__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cost, uint32_t* order, unsigned n)
+{
+    __shared__ unsigned s_max;
+    __shared__ unsigned s_bin[256];
+    if (threadIdx.x == 0) s_max = 1u;
+    if (threadIdx.x < 256) s_bin[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned m = 0;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) m = max(m, cost[i]);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const float scale = 255.0f / (float)s_max;
+    auto cls = [&](unsigned c) { return 255u - min(255u, (unsigned)((float)c * scale)); };  // class 0 = heaviest
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_bin[cls(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive prefix: where each class begins
+        unsigned at = 0;
+        for (int b = 0; b < 256; b++) {
+            const unsigned c = s_bin[b];
+            s_bin[b] = at;
+            at += c;
+        }
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&s_bin[cls(cost[i])], 1u)] = i;
 }
 
 // ---------------------------------------------------------------- rows kernel
@@ -2475,6 +2513,12 @@ void rt_bvh_step_counts(unsigned long long out[4])
 #endif
 
 size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4); }
+
+hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, hipStream_t st)
+{
+    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, st, cost, order, n);
+    return hipGetLastError();
+}
 
 hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st)
 {

@@ -380,6 +380,43 @@ def test_tile_rows_and_frame_stride_split(rt, default_scene, rtiow_scene, scene_
     np.testing.assert_allclose(a + b, full, rtol=1e-6, atol=1e-6)
 
 
+def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
+    """From 16 frames per dispatch on, the lite kernel hands out its tiles heaviest first, by the ray
+    counts the previous dispatch of the same region left behind -- also after a resize and for a
+    band of tile rows.  The order must not show in the image."""
+    w, h = 200, 120
+    ubo = default_scene.camera.copy()
+    ubo["frameCount"][0] = 1
+    with rt.Renderer(64, 64) as r:
+        r.set_kernel(rt.KERNEL_LITE)
+        r.set_max_depth(12)
+        r.upload_spheres(default_scene.spheres)
+        r.set_uniforms(ubo)
+        r.dispatch(16)   # another image size first: the cost array is reallocated below
+        r.resize(w, h)
+        total = 0
+        for k in range(3):
+            u = ubo.copy()
+            u["frameCount"][0] = 1 + 16 * k
+            r.set_uniforms(u)
+            r.reset_counters()
+            r.dispatch(16)
+            total += r.counters()["rays"]
+        acc, col = r.read_accum(), r.read_color()
+        cacc, ccol, crays = O.render(ubo, default_scene.spheres, w, h, n_frames=48, max_depth=12)
+        assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
+        # a band of tile rows: another region, so the first dispatch runs in image order again
+        r.set_tile_rows(3, 11)
+        for k in range(2):
+            u = ubo.copy()
+            u["frameCount"][0] = 1 + 16 * k
+            r.set_uniforms(u)
+            r.dispatch(16)
+        band = r.read_accum()
+        cband, _, _ = O.render(ubo, default_scene.spheres, w, h, n_frames=32, max_depth=12, rows=(3, 11), accum=cacc.copy())
+        assert np.array_equal(_bits(band[24:88]), _bits(cband[24:88]))
+
+
 def test_two_frames_in_flight(rt, default_scene):
     """rt_bind_buffers_next + rt_sync_dispatch(1): frames traced alternately into two caller-owned
     colour images, frame f dispatched before frame f-1 is waited for (the reference's two frames in
