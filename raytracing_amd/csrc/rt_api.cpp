@@ -695,6 +695,45 @@ int launch_rows(rt_context* c, RtParams& P, bool fused)
     return RT_OK;
 }
 
+// Tiles in descending order of their cost in the previous dispatch of the same region, for the
+// kernels that hand out whole tiles or spans of pixels (rt_tile_order_kernel): fills P.tile_cost
+// (where this dispatch leaves its costs) and, when the costs of the previous one are known,
+// P.tile_order.  zero_cost: the kernel adds to the costs instead of storing them.  Does nothing
+// (image order) when the arrays cannot be allocated.
+void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost)
+{
+    const unsigned ntiles = P.total_pixels / 64u;
+    const int region[4] = {P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows};
+    P.tile_cost = nullptr;
+    P.tile_order = nullptr;
+    if (ntiles > c->tile_cap) {
+        if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+        if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+        c->d_tile_cost = c->d_tile_order = nullptr;
+        c->tile_cap = c->cost_tiles = 0;
+        if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 4) == hipSuccess &&
+            hipMalloc(&c->d_tile_order, (size_t)ntiles * 4) == hipSuccess) {
+            c->tile_cap = ntiles;
+        } else {
+            if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+            c->d_tile_cost = c->d_tile_order = nullptr;
+            (void)hipGetLastError();
+            return;
+        }
+    }
+    const bool known = c->cost_tiles == ntiles && memcmp(region, c->cost_region, sizeof region) == 0;
+    if (known && order_now && rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, c->stream) == hipSuccess)
+        P.tile_order = c->d_tile_order;
+    if (zero_cost && hipMemsetAsync(c->d_tile_cost, 0, (size_t)ntiles * 4, c->stream) != hipSuccess) {
+        P.tile_order = nullptr;
+        c->cost_tiles = 0;
+        return;
+    }
+    P.tile_cost = c->d_tile_cost;
+    c->cost_tiles = ntiles;  // valid once this dispatch has run (the stream is in order)
+    memcpy(c->cost_region, region, sizeof region);
+}
+
 int launch(rt_context* c, const RtParams& P_in, bool record)
 {
     RtParams P = P_in;
@@ -726,33 +765,8 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             // (rt_tile_order_kernel; 10 us for a 1080p image, 70 us for 4K).  Measured on the default scene:
             // 1920x1080 x 64 frames 2.98 -> 2.47 ms, x 8 frames 394 -> 385 us; 3840x2160 x 8 frames 1.27 -> 1.37 ms.
             static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 16);  // development knob; < 0: never
-            const unsigned ntiles = P.total_pixels / 64u;
-            const int region[4] = {P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows};
-            if (lpt_min_frames >= 0 && ntiles > c->tile_cap) {
-                if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
-                if (c->d_tile_order) (void)hipFree(c->d_tile_order);
-                c->d_tile_cost = c->d_tile_order = nullptr;
-                c->tile_cap = c->cost_tiles = 0;
-                if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 4) == hipSuccess &&
-                    hipMalloc(&c->d_tile_order, (size_t)ntiles * 4) == hipSuccess) {
-                    c->tile_cap = ntiles;
-                } else {  // no room: the dispatch runs in image order
-                    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
-                    c->d_tile_cost = c->d_tile_order = nullptr;
-                    (void)hipGetLastError();
-                }
-            }
-            const bool known = c->cost_tiles == ntiles && memcmp(region, c->cost_region, sizeof region) == 0;
-            P.tile_cost = lpt_min_frames >= 0 && c->tile_cap >= ntiles ? c->d_tile_cost : nullptr;
-            P.tile_order = nullptr;
-            if (P.tile_cost && known && P.n_frames >= lpt_min_frames &&
-                rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, c->stream) == hipSuccess)
-                P.tile_order = c->d_tile_order;
+            if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false);
             e = rt_launch_lite(P, fused, threads, c->stream);
-            if (e == hipSuccess && P.tile_cost) {
-                c->cost_tiles = ntiles;
-                memcpy(c->cost_region, region, sizeof region);
-            }
         }
         if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
         c->last_mode = 4;
@@ -796,6 +810,14 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         if (mode == 4 && rt_stream_lds_bytes(P.n_lds, threads, false, P.n_bounds * 3 / 2) > kLdsPerCu)
             return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     }
+    // Brute-force modes, large scenes: spans of the heaviest tiles first.  The end of a dispatch is a few deep
+    // pixels taken late, each a chain of (frames x depth) passes, and a pass grows with the scene.  Measured at
+    // 3840x2160: 4096 spheres 16.5 -> 15.5 ms, 1000 spheres 13.4 -> 11.6 ms; but 484 spheres 9.63 -> 9.90 ms and
+    // 200 spheres 4.82 -> 5.13 ms (the sort of 129 600 tiles and the cost atomics outweigh the shorter tail).
+    static const int lpt_min_spheres = env_int("RT_DEBUG_LPT_STREAM_SPHERES", 1000);  // development knob; < 0: never
+    if (!record && (mode == 0 || mode == 1 || mode == 3 || mode == 5) && lpt_min_spheres >= 0 &&
+        P.sphere_count >= lpt_min_spheres && (long long)P.total_pixels * P.n_frames >= (1 << 22))
+        use_tile_order(c, P, true, true);
     hipError_t e = hipSuccess;
     if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
         c->fail_next_launch = false;

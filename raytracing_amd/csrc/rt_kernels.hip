@@ -1925,7 +1925,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     uint32_t px = 0, py = 0, frame = 0;
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned nrays = 0;
+    unsigned nrays = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
 #ifdef RT_COUNT_PASSES
     unsigned npasses = 0;  // experiment: passes over the sphere list, added to the word after the ray counter
 #endif
@@ -1979,7 +1979,9 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             const uint32_t rank = mbcnt64(freem);
             if (!alive && rank < navail) {
                 const uint32_t pix = span_cur + rank;
-                const uint32_t tile = pix >> 6, l = pix & 63u;
+                const uint32_t l = pix & 63u;
+                // span -> tile: heaviest tiles of the previous dispatch first when their costs are known
+                const uint32_t tile = P.tile_order ? P.tile_order[pix >> 6] : pix >> 6;
                 // tile / tile_cols by multiplication: exact for tile < 2^24 (checked on the host)
                 const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
                 const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
@@ -1987,6 +1989,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                 py = ((uint32_t)P.tile_row0 + ty) * 8 + (l >> 3);
                 primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
                 j = 0;
+                pixel_rays0 = nrays;
                 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (!RECORD)
                     if (!clear_at(P, 0, P.frame0)) acc = P.accum[(size_t)py * P.width + px];
@@ -2145,7 +2148,13 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                 acc.w = 1.0f + acc.w;
                 j++;
                 if (j == P.n_frames) {
-                    if constexpr (!RECORD) store_pixel(P, px, py, acc);
+                    if constexpr (!RECORD) {
+                        store_pixel(P, px, py, acc);
+                        if (P.tile_cost != nullptr)  // the pixel's rays go to its tile's cost, for the next dispatch's order
+                            atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +
+                                          ((px >> 3) - (uint32_t)P.tile_col0),
+                                      nrays - pixel_rays0);
+                    }
                     alive = false;
                 } else {
                     start = true;
