@@ -810,13 +810,16 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         if (mode == 4 && rt_stream_lds_bytes(P.n_lds, threads, false, P.n_bounds * 3 / 2) > kLdsPerCu)
             return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     }
-    // Brute-force modes, large scenes: spans of the heaviest tiles first.  The end of a dispatch is a few deep
-    // pixels taken late, each a chain of (frames x depth) passes, and a pass grows with the scene.  Measured at
-    // 3840x2160: 4096 spheres 16.5 -> 15.5 ms, 1000 spheres 13.4 -> 11.6 ms; but 484 spheres 9.63 -> 9.90 ms and
+    // Large scenes: spans of the heaviest tiles first.  The end of a dispatch is a few deep pixels taken late,
+    // each a chain of (frames x depth) passes, and a pass grows with the scene.  Measured at 3840x2160, brute
+    // force: 4096 spheres 16.5 -> 15.5 ms, 1000 spheres 13.4 -> 11.6 ms; but 484 spheres 9.63 -> 9.90 ms and
     // 200 spheres 4.82 -> 5.13 ms (the sort of 129 600 tiles and the cost atomics outweigh the shorter tail).
+    // Culled and bvh kernels out of LDS: 1000 spheres 13.3 -> 9.1 ms (bvh) and 19.3 -> 13.8 ms (culled), 4096
+    // spheres 5.8 -> 4.7 ms and 20.9 -> 16.3 ms.  The bvh kernel out of global memory is left as it is
+    // (16 384 spheres 4.35 -> 4.75 ms: its dispatch is short and its tail is not what bounds it).
     static const int lpt_min_spheres = env_int("RT_DEBUG_LPT_STREAM_SPHERES", 1000);  // development knob; < 0: never
-    if (!record && (mode == 0 || mode == 1 || mode == 3 || mode == 5) && lpt_min_spheres >= 0 &&
-        P.sphere_count >= lpt_min_spheres && (long long)P.total_pixels * P.n_frames >= (1 << 22))
+    if (!record && mode != 6 && lpt_min_spheres >= 0 && P.sphere_count >= lpt_min_spheres &&
+        (long long)P.total_pixels * P.n_frames >= (1 << 22))
         use_tile_order(c, P, true, true);
     hipError_t e = hipSuccess;
     if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were

@@ -418,15 +418,16 @@ def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
 
 
 def test_span_order_of_large_scenes_does_not_show(rt):
-    """From 1000 spheres and 4 M paths per dispatch on, the stream kernel takes its spans heaviest
-    tile first, by the ray counts the previous dispatch left behind.  Second and third dispatch
-    (ordered) against the tile kernel (never ordered), whole image; and the oracle on a crop."""
+    """From 1000 spheres and 4 M paths per dispatch on, the stream kernel (brute force, culled and
+    bvh alike) takes its spans heaviest tile first, by the ray counts the previous dispatch left
+    behind.  Second and third dispatch (ordered) against the tile kernel (never ordered), whole
+    image; and the oracle on a crop."""
     scene = rt.Scene.generate(rt.KIND_CUBE, 1000, 13)
     w, h = 2048, 1024
     ubo = scene.camera.copy()
     ubo["frameCount"][0] = 1
     out = {}
-    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
+    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_STREAM_CULLED, rt.KERNEL_BVH, rt.KERNEL_TILE):
         with rt.Renderer(w, h) as r:
             r.set_kernel(kernel)
             r.set_max_depth(6)
@@ -437,8 +438,10 @@ def test_span_order_of_large_scenes_does_not_show(rt):
                 r.set_uniforms(u)
                 r.dispatch(2)
             out[kernel] = (r.read_accum(), r.read_color(), r.counters()["rays"])
-    a, b = out[rt.KERNEL_STREAM], out[rt.KERNEL_TILE]
-    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    b = out[rt.KERNEL_TILE]
+    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_STREAM_CULLED, rt.KERNEL_BVH):
+        a = out[kernel]
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2], kernel
     cacc, _, _ = O.render(ubo, scene.spheres, w, h, n_frames=6, max_depth=6, rows=(60, 62), threads=8)
     assert np.array_equal(_bits(a[0][480:496]), _bits(cacc[480:496]))
 
