@@ -610,6 +610,31 @@ typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
 #define RT_GROUP_LDS 4
 #endif
 
+// Minimum of v over the 64 lanes of a wave whose lanes are all active, as a wave-uniform value:
+// two quad permutations and the two row mirrors leave every row of 16 lanes with its minimum (DPP,
+// no LDS traffic), and the four rows meet on the scalar side.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));  // row_mirror
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ float lane_value(float v, int from)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from));
+}
+
+// Paths still running in a wave at or below which rt_lite_kernel traces them one at a time with
+// the whole wave (below).
+#ifndef RT_LITE_TEAM_MAX
+#define RT_LITE_TEAM_MAX 4
+#endif
+
 // ---------------------------------------------------------------- lite kernel
 
 // Scenes of at most 64 traced spheres (the reference's default scene traces 40).  A pass over so
@@ -623,6 +648,12 @@ typedef const v4f __attribute__((address_space(4)))* ConstGeomPtr;
 //   - a lane runs the frames of its pixel back to back on its own: when its path ends it starts
 //     the next frame at once instead of waiting for the slowest path of the tile, so over a
 //     dispatch of many frames the lanes of a wave stay busy (their sums of bounces even out).
+//   - when only a few lanes are left with a path (RT_LITE_TEAM_MAX; the mirror chains of up to
+//     max_depth bounces that a tile ends with, and that a dispatch of ONE frame ends with), a pass
+//     is no longer sieve + walk per lane -- some 400 dependent instructions for a lone ray -- but
+//     the literal test of every sphere at once: lane i holds sphere i, the ray is broadcast, every
+//     lane evaluates shader.comp:44-60 for its sphere and the wave takes the minimum t, lowest
+//     index among equal ones -- what the shader's strict `<` in index order keeps.
 // The workgroup first copies the sphere records and the sieve geometry into LDS and reads them
 // from there, the sieve in a loop over groups of sphere pairs that is not unrolled (see
 // rt_rows_kernel).  Through the scalar cache, as rt_stream_kernel reads the geometry, this kernel
@@ -662,15 +693,43 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     const int groups0 = two ? RT_CHUNK / 2 / PGROUP : last_groups;
     const int groups1 = two ? last_groups : 0;
 
+    // the lane's own sphere, for the passes that the whole wave spends on one ray
+    const bool own_valid = (int)lane < P.sphere_count;
+    const float4 own = smem[2 * lane];
+    const bool own_far = own_valid && P.materials != nullptr && P.materials[lane].x == 3.0f;
+
     int j = 0;
     uint32_t frame = P.frame0;
     unsigned nrays = 0;
     Path p;
     path_reset(p, P, d0x, d0y, d0z);
     bool alive = P.n_frames > 0;
-    while (__ballot(alive) != 0ull) {
-        // ---- Trace(): sieve + candidate walk (rt_stream_kernel has the commentary)
+    for (;;) {
+        const unsigned long long alive_mask = __ballot(alive);
+        if (alive_mask == 0ull) break;
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+        float best = RT_FLT_MAX;
+        int idx = -1;
+        if (__popcll(alive_mask) <= RT_LITE_TEAM_MAX) {  // wave-uniform
+            // ---- Trace() of the few rays left, one after the other, a sphere per lane
+            for (unsigned long long todo = alive_mask; todo != 0ull; todo &= todo - 1ull) {
+                const int from = (int)__builtin_ctzll(todo);
+                Path q;
+                q.ox = lane_value(p.ox, from); q.oy = lane_value(p.oy, from); q.oz = lane_value(p.oz, from);
+                q.dx = lane_value(p.dx, from); q.dy = lane_value(p.dy, from); q.dz = lane_value(p.dz, from);
+                float t = RT_FLT_MAX;  // stays there unless this lane's sphere is hit at 0 < t < FLT_MAX
+                int hit = -1;
+                if (own_valid)
+                    test_sphere<FUSED>(q, lane_value(a, from), own.x, own.y, own.z, own.w, (int)lane, t, hit, own_far);
+                const uint32_t nearest = wave_min_u32(__float_as_uint(t));  // t > 0: ordered as its bits
+                const unsigned long long at_nearest = __ballot(__float_as_uint(t) == nearest);
+                if ((int)lane == from && nearest != __float_as_uint(RT_FLT_MAX)) {
+                    best = __uint_as_float(nearest);
+                    idx = (int)__builtin_ctzll(at_nearest);
+                }
+            }
+        } else {
+        // ---- Trace(): sieve + candidate walk (rt_stream_kernel has the commentary)
         const SieveRay sr = sieve_ray(p, a, alive);
         // read from LDS anew in every pass: the offset is hidden from the optimiser, which would
         // otherwise keep the whole geometry in registers across passes
@@ -680,8 +739,6 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         const uint32_t cand0 = ~sieve_chunk_partial<PGROUP>(geom, sr, groups0) & valid0;
         uint32_t cand1 = 0u;
         if (two) cand1 = ~sieve_chunk_partial<PGROUP>(geom + RT_CHUNK, sr, groups1) & valid1;
-        float best = RT_FLT_MAX;
-        int idx = -1;
         uint32_t cur = cand0;
         int base = 0;
         for (;;) {
@@ -699,6 +756,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
                 const float4 g = smem[2 * i];
                 test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
             }
+        }
         }
         // ---- shade; a lane whose path has ended goes straight on to its pixel's next frame
         if (alive) {

@@ -124,9 +124,11 @@ struct RtParams {
                                  // pair-packed per axis, 3 float4 per pair of entries
     int n_block_boxes;           // block entries in `boxes` (a multiple of 8, at least RT_BVH_BLOCKS)
     const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
-    const uint32_t* tile_order;  // lite kernel: wave slot -> tile (tiles in descending order of their cost in the
-                                 // previous dispatch), or null: slot = tile
-    uint32_t* tile_cost;         // lite kernel: rays of each tile in this dispatch are left here (may be null)
+    const uint32_t* tile_order;  // lite and stream kernels: k-th tile handed out -> tile of the dispatched region
+                                 // (tiles in descending order of their cost in the previous dispatch), or null:
+                                 // image order
+    uint32_t* tile_cost;         // rays of each tile in this dispatch are left here (may be null): stored by the
+                                 // lite kernel, added pixel by pixel by the stream kernel (zeroed before the launch)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
     unsigned* work_counter;      // RT_WORK_BYTES block of queue counters; all zero between launches
