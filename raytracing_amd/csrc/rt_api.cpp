@@ -92,6 +92,8 @@ struct rt_context {
     uint32_t* d_tile_order = nullptr;
     unsigned tile_cap = 0;       // tiles both arrays have room for
     unsigned cost_tiles = 0;     // tiles d_tile_cost describes (0: nothing yet), for the region below
+    unsigned order_tiles = 0;    // tiles d_tile_order orders (0: nothing yet), for the same region
+    int order_uses = 0;          // dispatches that have used d_tile_order since it was sorted
     int cost_region[4] = {0, 0, 0, 0};  // tile_col0, tile_cols, tile_row0, tile_rows of that dispatch
     float4* d_boxes = nullptr;    // per-lane traversal: boxes of the groups, then of the blocks (3 float4 per pair)
     int* d_perm = nullptr;        // sorted slot -> index in d_spheres
@@ -695,13 +697,20 @@ int launch_rows(rt_context* c, RtParams& P, bool fused)
     return RT_OK;
 }
 
-// Tiles in descending order of their cost in the previous dispatch of the same region, for the
-// kernels that hand out whole tiles or spans of pixels (rt_tile_order_kernel): fills P.tile_cost
-// (where this dispatch leaves its costs) and, when the costs of the previous one are known,
-// P.tile_order.  zero_cost: the kernel adds to the costs instead of storing them.  Does nothing
-// (image order) when the arrays cannot be allocated.
+// Tiles in descending order of their cost in an earlier dispatch of the same region, for the
+// kernels that hand out whole tiles or spans of pixels (rt_tile_order_kernel): fills P.tile_order
+// when an order is at hand, and P.tile_cost (where this dispatch leaves its costs) when the next
+// dispatch will want to sort.  An order serves 8 dispatches: the sort is one workgroup's work
+// (measured under rocprofv3: 60 us for the 32 400 tiles of a 1080p image, 215 us for 4K) and what
+// it sorts by changes little from one dispatch of a region to the next -- and the order only says
+// who goes first, never what is computed.  Measured, an order used 1 / 4 / 8 times: default scene
+// 1080p x 64 frames 83.4 / 84.9 / 85.1 Grays/s, 4096 spheres 1.96 / 1.99 / 2.00.  zero_cost: the kernel adds to the
+// costs pixel by pixel instead of storing them tile by tile, so they are zeroed first, and
+// recorded only by the dispatch before a sort (an atomic per pixel is not free); stored costs are
+// recorded every time.  Does nothing (image order) when the arrays cannot be allocated.
 void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost)
 {
+    static const int uses = std::max(1, env_int("RT_DEBUG_LPT_USES", 8));  // development knob
     const unsigned ntiles = P.total_pixels / 64u;
     const int region[4] = {P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows};
     P.tile_cost = nullptr;
@@ -710,7 +719,7 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost)
         if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
         if (c->d_tile_order) (void)hipFree(c->d_tile_order);
         c->d_tile_cost = c->d_tile_order = nullptr;
-        c->tile_cap = c->cost_tiles = 0;
+        c->tile_cap = c->cost_tiles = c->order_tiles = 0;
         if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 4) == hipSuccess &&
             hipMalloc(&c->d_tile_order, (size_t)ntiles * 4) == hipSuccess) {
             c->tile_cap = ntiles;
@@ -721,17 +730,28 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost)
             return;
         }
     }
-    const bool known = c->cost_tiles == ntiles && memcmp(region, c->cost_region, sizeof region) == 0;
-    if (known && order_now && rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, c->stream) == hipSuccess)
-        P.tile_order = c->d_tile_order;
-    if (zero_cost && hipMemsetAsync(c->d_tile_cost, 0, (size_t)ntiles * 4, c->stream) != hipSuccess) {
-        P.tile_order = nullptr;
-        c->cost_tiles = 0;
-        return;
+    if (memcmp(region, c->cost_region, sizeof region) != 0) c->cost_tiles = c->order_tiles = 0;  // another region
+    memcpy(c->cost_region, region, sizeof region);
+    if (order_now) {
+        if (c->order_tiles == ntiles && c->order_uses < uses) {
+            c->order_uses++;
+            P.tile_order = c->d_tile_order;
+        } else if (c->cost_tiles == ntiles &&
+                   rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, c->stream) == hipSuccess) {
+            c->order_tiles = ntiles;
+            c->order_uses = 1;
+            P.tile_order = c->d_tile_order;
+        } else {
+            c->order_tiles = 0;
+        }
     }
+    c->cost_tiles = 0;
+    // will the next dispatch of this region sort?  (it may also not ask for an order at all: then the costs are unused)
+    const bool wanted = c->order_tiles != ntiles || c->order_uses >= uses;
+    if (zero_cost && (!wanted || hipMemsetAsync(c->d_tile_cost, 0, (size_t)ntiles * 4, c->stream) != hipSuccess))
+        return;
     P.tile_cost = c->d_tile_cost;
     c->cost_tiles = ntiles;  // valid once this dispatch has run (the stream is in order)
-    memcpy(c->cost_region, region, sizeof region);
 }
 
 int launch(rt_context* c, const RtParams& P_in, bool record)
@@ -762,7 +782,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             e = hipErrorLaunchFailure;
         } else {
             // Longest tiles first, from the costs the previous dispatch of the same region left behind
-            // (rt_tile_order_kernel; 10 us for a 1080p image, 70 us for 4K).  Measured on the default scene:
+            // (use_tile_order).  Measured on the default scene:
             // 1920x1080 x 64 frames 2.98 -> 2.47 ms, x 8 frames 394 -> 385 us; 3840x2160 x 8 frames 1.27 -> 1.37 ms.
             static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 16);  // development knob; < 0: never
             if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false);
