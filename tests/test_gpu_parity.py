@@ -395,7 +395,7 @@ def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
         r.dispatch(16)   # another image size first: the cost array is reallocated below
         r.resize(w, h)
         total = 0
-        for k in range(3):
+        for k in range(11):  # an order serves 8 dispatches: none, sorted, 7 x reused, sorted again, reused
             u = ubo.copy()
             u["frameCount"][0] = 1 + 16 * k
             r.set_uniforms(u)
@@ -403,7 +403,7 @@ def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
             r.dispatch(16)
             total += r.counters()["rays"]
         acc, col = r.read_accum(), r.read_color()
-        cacc, ccol, crays = O.render(ubo, default_scene.spheres, w, h, n_frames=48, max_depth=12)
+        cacc, ccol, crays = O.render(ubo, default_scene.spheres, w, h, n_frames=176, max_depth=12, threads=8)
         assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
         # a band of tile rows: another region, so the first dispatch runs in image order again
         r.set_tile_rows(3, 11)
@@ -420,8 +420,8 @@ def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
 def test_span_order_of_large_scenes_does_not_show(rt):
     """From 1000 spheres and 4 M paths per dispatch on, the stream kernel (brute force, culled and
     bvh alike) takes its spans heaviest tile first, by the ray counts the previous dispatch left
-    behind.  Second and third dispatch (ordered) against the tile kernel (never ordered), whole
-    image; and the oracle on a crop."""
+    behind, sorted anew every 8 dispatches.  Eleven dispatches (in image order, sorted, reused,
+    sorted again) against the tile kernel (never ordered), whole image; and the oracle on a crop."""
     scene = rt.Scene.generate(rt.KIND_CUBE, 1000, 13)
     w, h = 2048, 1024
     ubo = scene.camera.copy()
@@ -432,7 +432,7 @@ def test_span_order_of_large_scenes_does_not_show(rt):
             r.set_kernel(kernel)
             r.set_max_depth(6)
             r.upload_spheres(scene.spheres)
-            for k in range(3):
+            for k in range(11):
                 u = ubo.copy()
                 u["frameCount"][0] = 1 + 2 * k
                 r.set_uniforms(u)
@@ -442,7 +442,7 @@ def test_span_order_of_large_scenes_does_not_show(rt):
     for kernel in (rt.KERNEL_STREAM, rt.KERNEL_STREAM_CULLED, rt.KERNEL_BVH):
         a = out[kernel]
         assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2], kernel
-    cacc, _, _ = O.render(ubo, scene.spheres, w, h, n_frames=6, max_depth=6, rows=(60, 62), threads=8)
+    cacc, _, _ = O.render(ubo, scene.spheres, w, h, n_frames=22, max_depth=6, rows=(60, 62), threads=8)
     assert np.array_equal(_bits(a[0][480:496]), _bits(cacc[480:496]))
 
 
