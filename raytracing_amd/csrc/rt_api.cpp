@@ -553,10 +553,10 @@ void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const R
     const bool mfma = P.frags != nullptr && !far;  // the operand fragments are staged in LDS too: larger workgroups share them
     // matrix-core sieve: two waves per SIMD saturate it (measured: 8 waves per CU = 12 = 16); 256-thread
     // workgroups while two of them fit in LDS, else one of 512
-    const int t_mfma = rt_stream_lds_bytes(P.n_lds, 256, true) * 2 <= kLdsPerCu ? 256 : 512;
+    const int t_mfma = rt_stream_lds_bytes(P.n_lds, 256, true, 0, P.sg_wide) * 2 <= kLdsPerCu ? 256 : 512;
     int t = want_threads > 0 ? want_threads : (mfma ? t_mfma : P.n_lds <= 1024 ? 256 : RT_STREAM_MAX_THREADS);
     t = std::max(64, std::min(mfma ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS, t / 64 * 64));
-    const size_t lds = rt_stream_lds_bytes(P.n_lds, t, mfma);
+    const size_t lds = rt_stream_lds_bytes(P.n_lds, t, mfma, 0, P.sg_wide);
     const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
     int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)cu_count ? 8 : 12;
     if (mfma) waves_per_cu = 8;
@@ -800,9 +800,17 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     const bool mfma = wants_mfma(c, P);
     P.frags = mfma ? c->d_frags : nullptr;
     int blocks, threads;
-    stream_geometry(c, P, &blocks, &threads);
     const bool far = mfma && P.n_pad > RT_MAX_MFMA_SPHERES;
-    if (rt_stream_lds_bytes(P.n_lds, threads, mfma && !far) > kLdsPerCu)
+    // matrix-core sieve over more than 512 spheres that the walk reads from LDS: candidate walks every 1024
+    // spheres (RT_SG_CHUNKS_WIDE), if the masks still fit
+    static const int sg_wide = env_int("RT_DEBUG_SG_WIDE", 1);  // development knob: 0 = never
+    P.sg_wide = sg_wide && mfma && P.n_lds != 0 && P.n_pad > RT_SG_CHUNKS * RT_CHUNK;
+    stream_geometry(c, P, &blocks, &threads);
+    if (P.sg_wide && rt_stream_lds_bytes(P.n_lds, threads, mfma && !far, 0, true) > kLdsPerCu) {
+        P.sg_wide = 0;
+        stream_geometry(c, P, &blocks, &threads);
+    }
+    if (rt_stream_lds_bytes(P.n_lds, threads, mfma && !far, 0, P.sg_wide) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
     if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,

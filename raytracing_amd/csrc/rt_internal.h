@@ -8,7 +8,7 @@
 #include "rt_params.h"
 
 // ---- rt_kernels.hip
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma = false, int extra_float4 = 0);
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma = false, int extra_float4 = 0, bool sg_wide = false);
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st);
 hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,

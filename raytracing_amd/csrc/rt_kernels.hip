@@ -1899,7 +1899,7 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 
 // Persistent kernel.  blockDim.x is a multiple of 64 (<= RT_STREAM_MAX_THREADS); dynamic LDS =
 // rt_stream_lds_bytes(): n_pad*16 B sieve geometry + n_pad*4 B radii + per mode the matrix-core
-// operands or the group bounds + (blockDim.x/64) * RT_SG_CHUNKS*64*4 B masks.
+// operands or the group bounds + (blockDim.x/64) * RT_SG_CHUNKS (or RT_SG_CHUNKS_WIDE) * 64*4 B masks.
 //
 // MODE selects where the sieve reads the geometry from: 0 = the LDS copy (wave-uniform
 // ds_read_b128), 1 = global memory through the scalar cache (s_load into SGPRs, which the
@@ -1937,7 +1937,8 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     for (int i = threadIdx.x; i < n_frag; i += blockDim.x)
         frags[i] = BVH ? reinterpret_cast<const uint4*>(P.boxes)[i] : P.frags[i];
     __syncthreads();  // the only barrier: waves run independently from here on
-    uint32_t* wmask = reinterpret_cast<uint32_t*>(frags + n_frag) + wave * (RT_SG_CHUNKS * 64);
+    const int sg_chunks = !SORTED && P.sg_wide ? RT_SG_CHUNKS_WIDE : RT_SG_CHUNKS;  // chunks between candidate walks
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(frags + n_frag) + wave * (sg_chunks * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
@@ -2093,8 +2094,8 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                 mr = mfma_ray(p, a);
             else
                 sr = sieve_ray(p, a, alive);
-            for (int sg = 0; sg < nch; sg += RT_SG_CHUNKS) {
-                const int nsg = min(RT_SG_CHUNKS, nch - sg);
+            for (int sg = 0; sg < nch; sg += sg_chunks) {
+                const int nsg = min(sg_chunks, nch - sg);
                 uint32_t summary = 0;
                 // culled kernel: bit (63 - n) of `wneed` = some lane's ray may touch group n of
                 // this supergroup (4 groups of 8 spheres per chunk)
@@ -2493,10 +2494,11 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4)
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4, bool sg_wide)
 {
     return (size_t)n_lds * (sizeof(float4) + sizeof(float) + (mfma ? 4 * sizeof(uint4) : 0)) +
-           (size_t)extra_float4 * sizeof(float4) + (size_t)(threads / 64) * RT_SG_CHUNKS * 64 * sizeof(uint32_t);
+           (size_t)extra_float4 * sizeof(float4) +
+           (size_t)(threads / 64) * (sg_wide ? RT_SG_CHUNKS_WIDE : RT_SG_CHUNKS) * 64 * sizeof(uint32_t);
 }
 
 // mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
@@ -2508,7 +2510,8 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
 {
     if (threads < 64 || threads % 64 != 0 || threads > (mode == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS))
         return hipErrorInvalidConfiguration;  // beyond the instantiation's launch bounds
-    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0);
+    const bool sorted = mode == 2 || mode == 4 || mode == 6;
+    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0, !sorted && P.sg_wide);
     static const size_t pad = [] {
         const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
         return e ? (size_t)atol(e) : (size_t)0;

@@ -17,6 +17,11 @@ struct RtSphereAos {
 // per-lane candidate walk.
 constexpr int RT_CHUNK = 32;
 constexpr int RT_SG_CHUNKS = 16;
+// ... or of RT_SG_CHUNKS_WIDE chunks (RtParams::sg_wide; matrix-core sieve, 1025 to 4096 spheres).  A walk
+// lasts until the lane with the most candidates is done, and over twice the spheres the lanes' counts are
+// closer to one another: measured at 3840x2160, 4096 spheres 15.3 -> 14.8 ms, 1000 spheres 11.1 -> 10.8 ms
+// (16 384 spheres, where the walk reads global memory: 26.7 -> 29.0 ms, so not there).
+constexpr int RT_SG_CHUNKS_WIDE = 32;
 // Largest sphere count whose geometry stream is staged in LDS (16 B per sphere).
 #ifndef RT_MAX_LDS
 #define RT_MAX_LDS 4096
@@ -124,6 +129,8 @@ struct RtParams {
                                  // pair-packed per axis, 3 float4 per pair of entries
     int n_block_boxes;           // block entries in `boxes` (a multiple of 8, at least RT_BVH_BLOCKS)
     const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
+    int sg_wide;                 // != 0: candidate walks every RT_SG_CHUNKS_WIDE chunks instead of every RT_SG_CHUNKS
+                                 // (brute-force kernels only; the masks in LDS are sized to match)
     const uint32_t* tile_order;  // lite and stream kernels: k-th tile handed out -> tile of the dispatched region
                                  // (tiles in descending order of their cost in the previous dispatch), or null:
                                  // image order
