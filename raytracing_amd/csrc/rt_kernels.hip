@@ -1411,10 +1411,15 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
 {
     uint32_t summary = 0;
     v16f SA, TA, SB, TB;
-    // chunk c from the fragments (p0, p1), whose first tile is already in (SA, TA); the first tile of
-    // the chunk after it, fragments (n0, n1), is issued in between
-    auto step = [&](const v8bf& p0, const v8bf& p1, const v8bf& n0, const v8bf& n1, int c) {
-        mfma_tile(p0, p1, r, 1, SB, TB);
+    v8bf a0 = frag[lane], a1 = frag[64 + lane];
+    mfma_tile(a0, a1, r, 0, SA, TA);
+    for (int c = 0; c < nsg; c++) {
+        // the next chunk's fragments are on their way while this chunk is worked on (the last
+        // chunk "prefetches" itself: its extra tile is computed and dropped, which keeps the loop
+        // body free of branches for the instruction scheduler)
+        const int cn = min(c + 1, nsg - 1);
+        const v8bf n0 = frag[cn * 128 + lane], n1 = frag[cn * 128 + 64 + lane];
+        mfma_tile(a0, a1, r, 1, SB, TB);
         const uint32_t m0 = tile_mask(SA, TA);
         // one MFMA, then the eight vector instructions of four accumulator registers: the matrix
         // pipe takes 32 cycles per MFMA, the vector instructions fit beside it
@@ -1430,6 +1435,8 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
         }
+        a0 = n0;
+        a1 = n1;
         // lower lanes own ray group 0, upper lanes group 1: after the swap .x holds spheres 0..15
         // and .y spheres 16..31 of the lane's own ray
         const v2u own = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
@@ -1438,24 +1445,7 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
         if (!alive) cand = 0u;  // an idle lane has no candidates
         wmask[c * 64 + lane] = cand;
         summary = (summary << 1) | (cand != 0u ? 1u : 0u);
-    };
-    // The next chunk's fragments are on their way while a chunk is worked on.  Two chunks per trip,
-    // the two fragment register sets taking turns, so that no set is ever copied into the other
-    // (one chunk per trip cost 6 register moves beside its 64 + 8 instructions).  The last chunk
-    // "prefetches" itself: its extra tile is computed and dropped, which keeps the steps free of
-    // branches for the instruction scheduler.
-    v8bf a0 = frag[lane], a1 = frag[64 + lane];
-    mfma_tile(a0, a1, r, 0, SA, TA);
-    int c = 0;
-    for (; c + 1 < nsg; c += 2) {
-        const v8bf b0 = frag[(c + 1) * 128 + lane], b1 = frag[(c + 1) * 128 + 64 + lane];
-        step(a0, a1, b0, b1, c);
-        const int cn = min(c + 2, nsg - 1);
-        a0 = frag[cn * 128 + lane];
-        a1 = frag[cn * 128 + 64 + lane];
-        step(b0, b1, a0, a1, c + 1);
     }
-    if (c < nsg) step(a0, a1, a0, a1, c);
     return summary << (32 - nsg);
 }
 
