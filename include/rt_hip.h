@@ -240,7 +240,10 @@ int rt_debug_math(rt_context* ctx, int op, const float* a, const float* b, const
    it with the shader's literal discriminant.  out[0], out[1]: spheres the sieve rejected
    although the discriminant under the STRICT / FUSED profile was not negative (must be
    0); out[2]: spheres with a non-negative STRICT discriminant; out[3]: spheres the sieve
-   passed.  No reference counterpart. */
+   passed.  The matrix-core sieve, when no materials are uploaded, also rejects spheres
+   behind the ray's origin: for it "discriminant not negative" reads "discriminant not
+   negative and b < 0" (what the shader goes on to take the root of) in out[0..2].
+   No reference counterpart. */
 int rt_debug_sieve_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t out[4]);
 
 /* Test hook for RT_KERNEL_STREAM_CULLED and RT_KERNEL_BVH: runs their culling tests on n_rays

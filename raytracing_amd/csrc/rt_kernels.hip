@@ -1348,8 +1348,31 @@ __device__ __forceinline__ MfmaRay mfma_ray(const Path& p, float a)
     return r;
 }
 
+// Sign bits of g = s^2 + t over a tile's 16 accumulator registers, first register in bit 15.
+// BEHIND: g = t - s |s| instead, which is the same for s < 0 and rejects as well what lies behind
+// the ray's origin as seen from outside the sphere -- the abs and neg modifiers of v_fma_f32 cost
+// nothing.  s = n.(o - c) has the sign of the shader's b = 2 dot(oc, d), and the shader takes a hit
+// only when b < 0 (test_sphere; with the material extension a dielectric sphere also when b >= 0,
+// so then BEHIND is off).  A sphere the shader can take has b < 0 as computed, hence s < 40u (|o| +
+// |c|) as computed here (u = 2^-24; both roundings), and where 0 <= s is that small t - s^2 differs
+// from t + s^2 by 2 s^2 < 10^-11 (|o| + |c|)^2, five orders of magnitude inside the margin's
+// slack.  With the origin inside the sphere t > s^2 anyway and nothing changes.
+template <bool BEHIND>
+__device__ __forceinline__ uint32_t tile_mask(const v16f& S, const v16f& T)
+{
+    uint32_t mask = 0;
+    // (one v_fma_f32 per accumulator register: measured, v_pk_fma_f32 on register pairs is 5 % slower here)
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const float g = BEHIND ? __builtin_fmaf(S[v], -__builtin_fabsf(S[v]), T[v]) : __builtin_fmaf(S[v], S[v], T[v]);
+        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(g), 31);
+    }
+    return mask;
+}
+
 // Sieve of one chunk: frag points at the chunk's two steps of 64 lane fragments in LDS.  Same
 // result convention as sieve_chunk: bit (31-n) SET when sphere n of the chunk is rejected.
+template <bool BEHIND>
 __device__ __forceinline__ uint32_t sieve_chunk_mfma(const v8bf* frag, int lane, const MfmaRay& r)
 {
     const v8bf a0 = frag[lane], a1 = frag[64 + lane];
@@ -1361,11 +1384,7 @@ __device__ __forceinline__ uint32_t sieve_chunk_mfma(const v8bf* frag, int lane,
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.s1[g], S, 0, 0, 0);
         v16f T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, r.t0[g], zero, 0, 0, 0);
         T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.t1[g], T, 0, 0, 0);
-        uint32_t mask = 0;
-#pragma unroll
-        for (int v = 0; v < 16; v++)
-            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(S[v], S[v], T[v])), 31);
-        m[g] = mask;  // spheres 16 h .. 16 h + 15 of ray 32 g + (lane & 31), h = lane >> 5
+        m[g] = tile_mask<BEHIND>(S, T);  // spheres 16 h .. 16 h + 15 of ray 32 g + (lane & 31), h = lane >> 5
     }
     // lower lanes own group 0, upper lanes group 1: m[0] keeps its lower half and takes m[1]'s
     // lower half (spheres 0..15 of the upper lanes' own rays) into its upper half, and so on
@@ -1389,22 +1408,12 @@ __device__ __forceinline__ void mfma_tile(v8bf a0, v8bf a1, const MfmaRay& r, in
     T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, r.t1[g], T, 0, 0, 0);
 }
 
-// Sign bits of g = s^2 + t over a tile's 16 accumulator registers, first register in bit 15.
-__device__ __forceinline__ uint32_t tile_mask(const v16f& S, const v16f& T)
-{
-    uint32_t mask = 0;
-    // (one v_fma_f32 per accumulator register: measured, v_pk_fma_f32 on register pairs is 5 % slower here)
-#pragma unroll
-    for (int v = 0; v < 16; v++)
-        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(__builtin_fmaf(S[v], S[v], T[v])), 31);
-    return mask;
-}
-
 // Matrix-core sieve of `nsg` consecutive chunks (frag = the first one's fragments in LDS),
 // software-pipelined by one tile: the MFMAs of the next tile are issued before the vector
 // instructions that read the current tile's accumulators, so that a wave keeps both pipes busy
 // by itself.  Writes the candidate masks of the chunks to wmask[c * 64 + lane] and returns the
 // summary (bit 31 - c set when chunk c has a candidate for this lane).
+template <bool BEHIND>
 __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg, int lane, const MfmaRay& r,
                                                       bool alive, bool has_last, uint32_t last_valid,
                                                       uint32_t* wmask)
@@ -1420,7 +1429,7 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
         const int cn = min(c + 1, nsg - 1);
         const v8bf n0 = frag[cn * 128 + lane], n1 = frag[cn * 128 + 64 + lane];
         mfma_tile(a0, a1, r, 1, SB, TB);
-        const uint32_t m0 = tile_mask(SA, TA);
+        const uint32_t m0 = tile_mask<BEHIND>(SA, TA);
         // one MFMA, then the eight vector instructions of four accumulator registers: the matrix
         // pipe takes 32 cycles per MFMA, the vector instructions fit beside it
 #pragma unroll
@@ -1429,7 +1438,7 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
             __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
         }
         mfma_tile(n0, n1, r, 0, SA, TA);
-        const uint32_t m1 = tile_mask(SB, TB);
+        const uint32_t m1 = tile_mask<BEHIND>(SB, TB);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1455,7 +1464,7 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg,
 // loads run AHEAD chunks in front of the arithmetic through a ring of AHEAD register pairs.  The
 // loop is unrolled AHEAD times so that the ring is addressed statically; the chunks are taken in
 // runs of AHEAD, a run that overshoots `nsg` recomputes the last chunk and drops the result.
-template <int AHEAD>
+template <int AHEAD, bool BEHIND>
 __device__ __forceinline__ uint32_t sieve_chunks_mfma_far(const v8bf* __restrict__ frag, int nsg, int lane,
                                                           const MfmaRay& r, bool alive, bool has_last,
                                                           uint32_t last_valid, uint32_t* wmask)
@@ -1482,14 +1491,14 @@ __device__ __forceinline__ uint32_t sieve_chunks_mfma_far(const v8bf* __restrict
             // slot k is free once its second tile has been issued: chunk c + AHEAD goes there
             q0[k] = frag[cn * 128 + lane];
             q1[k] = frag[cn * 128 + 64 + lane];
-            const uint32_t m0 = tile_mask(SA, TA);
+            const uint32_t m0 = tile_mask<BEHIND>(SA, TA);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, RT_MFMA_VALU_GROUP, 0);
             }
             mfma_tile(q0[(k + 1) % AHEAD], q1[(k + 1) % AHEAD], r, 0, SA, TA);
-            const uint32_t m1 = tile_mask(SB, TB);
+            const uint32_t m1 = tile_mask<BEHIND>(SB, TB);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -2121,12 +2130,19 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                     wneed = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)need0) << 32) |
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)need1);
                 }
+                // (matrix-core sieve: without the material extension it also rejects what lies behind the ray)
                 if constexpr (FAR_FRAGS) {
-                    summary = sieve_chunks_mfma_far<RT_MFMA_AHEAD>(reinterpret_cast<const v8bf*>(P.frags) + sg * 128, nsg, lane, mr,
-                                                                   alive, sg + nsg == nch, P.last_chunk_valid, wmask);
+                    const v8bf* fr = reinterpret_cast<const v8bf*>(P.frags) + sg * 128;
+                    summary = P.materials == nullptr
+                                  ? sieve_chunks_mfma_far<RT_MFMA_AHEAD, true>(fr, nsg, lane, mr, alive, sg + nsg == nch,
+                                                                               P.last_chunk_valid, wmask)
+                                  : sieve_chunks_mfma_far<RT_MFMA_AHEAD, false>(fr, nsg, lane, mr, alive, sg + nsg == nch,
+                                                                                P.last_chunk_valid, wmask);
                 } else if constexpr (MFMA) {
-                    summary = sieve_chunks_mfma(reinterpret_cast<const v8bf*>(frags) + sg * 128, nsg, lane, mr, alive,
-                                                sg + nsg == nch, P.last_chunk_valid, wmask);
+                    const v8bf* fr = reinterpret_cast<const v8bf*>(frags) + sg * 128;
+                    summary = P.materials == nullptr
+                                  ? sieve_chunks_mfma<true>(fr, nsg, lane, mr, alive, sg + nsg == nch, P.last_chunk_valid, wmask)
+                                  : sieve_chunks_mfma<false>(fr, nsg, lane, mr, alive, sg + nsg == nch, P.last_chunk_valid, wmask);
                 } else {
                     for (int c = 0; c < nsg; c++) {
                         constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
@@ -2275,13 +2291,17 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
 // compares every bit with the shader's literal discriminant under both float profiles.
 // out[0] / out[1]: spheres the sieve rejected although the STRICT / FUSED discriminant was not
 // negative (must stay 0); out[2]: spheres with a non-negative STRICT discriminant; out[3]: spheres
-// the sieve let through.  One lane per ray; blockDim.x = 256; dynamic LDS = n_pad*16 bytes.
+// the sieve let through.  The matrix-core sieve without the material extension also rejects what
+// lies behind the ray: there "discriminant not negative" reads "discriminant not negative and
+// b < 0", what test_sphere goes on to take the root of.
+// One lane per ray; blockDim.x = 256; dynamic LDS = n_pad*16 bytes.
 __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, const float* rays, int n_rays,
                                                             unsigned long long* out)
 {
     extern __shared__ float4 smem[];
     const bool mfma = P.frags != nullptr;  // audit the matrix-core sieve instead
     const bool far = mfma && P.n_pad > RT_MAX_MFMA_SPHERES;  // fragments read from global memory, as MODE 5 does
+    const bool behind = mfma && P.materials == nullptr;      // as rt_stream_kernel chooses
     uint4* frags = reinterpret_cast<uint4*>(smem + P.n_pad);
     for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) smem[i] = P.geom[i];
     for (int i = threadIdx.x; i < (mfma && !far ? P.n_pad * 4 : 0); i += blockDim.x) frags[i] = P.frags[i];
@@ -2297,10 +2317,10 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
     const SieveRay sr = sieve_ray(p, a_s, true);
     const MfmaRay mr = mfma_ray(p, a_s);
     for (int ch = 0; ch < P.n_pad / RT_CHUNK; ch++) {
-        const uint32_t rej =
-            far    ? sieve_chunk_mfma(reinterpret_cast<const v8bf*>(P.frags) + ch * 128, threadIdx.x & 63, mr)
-            : mfma ? sieve_chunk_mfma(reinterpret_cast<const v8bf*>(frags) + ch * 128, threadIdx.x & 63, mr)
-                   : sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
+        const v8bf* fr = reinterpret_cast<const v8bf*>(far ? P.frags : frags) + ch * 128;
+        const uint32_t rej = behind ? sieve_chunk_mfma<true>(fr, threadIdx.x & 63, mr)
+                             : mfma ? sieve_chunk_mfma<false>(fr, threadIdx.x & 63, mr)
+                                    : sieve_chunk<RT_GROUP_LDS>(reinterpret_cast<const v4f*>(smem) + ch * RT_CHUNK, sr);
         for (int n = 0; n < RT_CHUNK; n++) {
             const int i = ch * RT_CHUNK + n;
             if (i >= P.sphere_count || !live) break;
@@ -2313,8 +2333,8 @@ __global__ void __launch_bounds__(256) rt_sieve_audit_kernel(const RtParams P, c
             const float cf = mad<true>(-g.w, g.w, dot3<true>(ocx, ocy, ocz, ocx, ocy, ocz));
             const float df = mad<true>(bf, bf, -((4.0f * a_f) * cf));
             const bool rejected = (rej >> (31 - n)) & 1u;
-            if (!(ds < 0.0f)) { n_exact++; if (rejected) bad_s++; }
-            if (!(df < 0.0f) && rejected) bad_f++;
+            if (!(ds < 0.0f) && (bs < 0.0f || !behind)) { n_exact++; if (rejected) bad_s++; }
+            if (!(df < 0.0f) && (bf < 0.0f || !behind) && rejected) bad_f++;
             if (!rejected) n_sieve++;
         }
     }

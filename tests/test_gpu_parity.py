@@ -136,8 +136,9 @@ def test_sieve_never_rejects_a_literal_candidate(rt, default_scene, rtiow_scene,
     """The stream kernel rejects spheres with a cheap conservative test before it evaluates the
     shader's expressions: on the vector ALU (fma chains) or on the matrix cores (bf16-split
     operands).  Audit both directly: on random, camera-like and limb-grazing rays no sphere with
-    a non-negative literal discriminant (either float profile) may be rejected, and the sieve
-    must still reject nearly everything the literal test rejects.  "far" is the default scene
+    a non-negative literal discriminant (either float profile) may be rejected (matrix cores: none
+    with a non-negative discriminant and b < 0 -- that sieve also drops what lies behind the
+    ray), and the sieve must still reject nearly everything the literal test rejects.  "far" is the default scene
     moved 3000 units from the origin, where the expanded form cancels hardest."""
     scene = {"default": default_scene, "rtiow": rtiow_scene}.get(scene_name)
     if scene_name.startswith("cube"):  # cube3000: the matrix-core sieve streams its operands from global memory
