@@ -332,15 +332,26 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
 
 
 def interactive_ubos(rt, n):
-    """The uniform blocks of the interactive workload's first n frames: a key tap every 40 frames
-    (one impulse along the view direction, src/application.cpp:44-47) fed through Scene::update at
-    dt = 1/60 s, so the accumulation resets (frameCount = 1) while the camera moves."""
+    """The uniform blocks of the interactive workload's first n frames.  Every 40 frames the view
+    key is tapped (acceleration along the view direction, src/application.cpp:44-47), the
+    opposite key 8 frames later brakes, and at frame 16 the remaining acceleration is cancelled,
+    all fed through Scene::update at dt = 1/60 s: the camera moves about one unit and comes to
+    rest, so some 14 frames of each 40 restart the accumulation (frameCount = 1) and the others add
+    to it.  Forward and backward taps alternate: the camera stays within a unit of where it
+    started, the scene in view."""
     scene = rt.Scene.default()
     fwd = scene.camera["camera_forward"][0].copy()
+    tap, brake = 60.0, 50.0
     out = []
     for i in range(n):
-        if i % 40 == 0:
-            scene.add_acceleration(*(fwd * 100.0).tolist())
+        k = i % 40
+        way = 1.0 if (i // 40) % 2 == 0 else -1.0
+        if k == 0:
+            scene.add_acceleration(*(fwd * (way * tap)).tolist())
+        elif k == 8:   # Scene::update scales the acceleration by 0.98 per frame
+            scene.add_acceleration(*(fwd * (-way * (tap * 0.98 ** 8 + brake))).tolist())
+        elif k == 16:
+            scene.add_acceleration(*(fwd * (way * brake * 0.98 ** 8)).tolist())
         scene.update(1.0 / 60.0)
         out.append(scene.camera.copy())
     return scene, out
@@ -409,8 +420,9 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"interactive: default scene (40 traced spheres), {w}x{h}, 1 frame per dispatch, max depth "
-                            f"{args.max_depth}, float profile {args.profile}, camera impulse every 40 frames through "
-                            "Scene::update (accumulation resets while it moves), uniforms set and dispatch issued per frame",
+                            f"{args.max_depth}, float profile {args.profile}, view key tapped every 40 frames and braked, through "
+                            "Scene::update (the camera moves a unit and rests: the accumulation restarts in about 14 "
+                            "frames of 40), uniforms set and dispatch issued per frame",
                 "parallelism": f"bands of 8x8-tile rows over {world} GPU(s); two frames in flight: frame f+1 is dispatched "
                                "before the host waits for frame f, whose rgba8 bands are then gathered to rank 0 (two "
                                "colour images); kernel time = HIP events around the timed region / launches",

@@ -708,9 +708,10 @@ int launch_rows(rt_context* c, RtParams& P, bool fused)
 // costs pixel by pixel instead of storing them tile by tile, so they are zeroed first, and
 // recorded only by the dispatch before a sort (an atomic per pixel is not free); stored costs are
 // recorded every time.  Does nothing (image order) when the arrays cannot be allocated.
-void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost)
+void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, int uses = 8)
 {
-    static const int uses = std::max(1, env_int("RT_DEBUG_LPT_USES", 8));  // development knob
+    static const int uses_env = env_int("RT_DEBUG_LPT_USES", 0);  // development knob
+    if (uses_env > 0) uses = uses_env;
     const unsigned ntiles = P.total_pixels / 64u;
     const int region[4] = {P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows};
     P.tile_cost = nullptr;
@@ -783,9 +784,13 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         } else {
             // Longest tiles first, from the costs the previous dispatch of the same region left behind
             // (use_tile_order).  Measured on the default scene:
-            // 1920x1080 x 64 frames 2.98 -> 2.47 ms, x 8 frames 394 -> 385 us; 3840x2160 x 8 frames 1.27 -> 1.37 ms.
-            static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 16);  // development knob; < 0: never
-            if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false);
+            // 1920x1080 x 64 frames 2.98 -> 2.47 ms; sorted before every dispatch, 3840x2160 x 8 frames 1.27 -> 1.37 ms.
+            // Dispatches of a few frames (the interactive loop: one) end with the tiles that hold a chain of
+            // mirror bounces, wherever in the image they are; the chains sit where the geometry puts them, frame
+            // after frame, so there an order serves 128 dispatches and its sort costs next to nothing: 1080p x 1
+            // frame 61.7 -> 56.6-57.6 us (an order for 8 dispatches: 61.7 -> 61.9; for 32: 58.0).
+            static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 1);  // development knob; < 0: never
+            if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false, P.n_frames >= 16 ? 8 : 128);
             e = rt_launch_lite(P, fused, threads, c->stream);
         }
         if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
