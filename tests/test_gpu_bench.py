@@ -59,6 +59,7 @@ def test_bench_single_rank_line(workload, unit):
         assert line["value"] > (1000.0 if workload != "stress4096" else 100.0)
     else:
         assert line["higher_is_better"] is False and line["value"] < 50.0
+        assert line["rays_per_path"] > 1.2  # the default scene in view: a camera looking at sky traces 1.0
     _check_roofline(line)
     cpu = line["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["value"] > 0

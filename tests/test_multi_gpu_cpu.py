@@ -178,3 +178,26 @@ def test_world_size_two_gloo(tmp_path, default_scene):
     for f, u in enumerate(ubos):
         acc, col, _ = O.render(u, default_scene.spheres, W, H, n_frames=1, accum=acc)
         assert np.array_equal(shown[f], col), f
+
+
+def test_interactive_camera_script_keeps_the_scene_in_view():
+    """bench.py's interactive workload taps the view key, brakes and releases, forward and backward in
+    turn: the camera must stay within two units of where it started (the default scene is 36 units
+    ahead), and every 40-frame period must both restart the accumulation (frameCount == 1 while the
+    camera moves more than 0.01 a frame, includes/scene.hpp:106-116) and add to it."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import raytracing_amd as rt
+
+    start = rt.Scene.default().camera["camera_position"][0].copy()
+    _, ubos = bench.interactive_ubos(rt, 440)
+    pos = np.array([u["camera_position"][0] for u in ubos])
+    count = np.array([int(u["frameCount"][0]) for u in ubos])
+    assert np.abs(pos - start).max() < 2.0
+    for p0 in range(0, 440, 40):
+        period = count[p0:p0 + 40]
+        assert 8 <= (period == 1).sum() <= 24 and period.max() >= 16, period
