@@ -624,6 +624,11 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return min(min(a, b), min(c, d));
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    return ~wave_min_u32(~v);
+}
+
 __device__ __forceinline__ float lane_value(float v, int from)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from));
@@ -654,6 +659,11 @@ __device__ __forceinline__ float lane_value(float v, int from)
 //     the literal test of every sphere at once: lane i holds sphere i, the ray is broadcast, every
 //     lane evaluates shader.comp:44-60 for its sphere and the wave takes the minimum t, lowest
 //     index among equal ones -- what the shader's strict `<` in index order keeps.
+//   - the first pass of a wave is the camera rays of its 64 pixels: one origin, directions within
+//     half a degree of one another.  Lane i tests sphere i against the cone that holds them all
+//     (tile_cone_keeps), the ballot is the tile's candidate list, and every lane runs the literal
+//     test on just those, in index order and without divergence -- in place of 40 sieve tests and
+//     a walk as long as the busiest lane's.  A dispatch of one frame is mostly this pass.
 // The workgroup first copies the sphere records and the sieve geometry into LDS and reads them
 // from there, the sieve in a loop over groups of sphere pairs that is not unrolled (see
 // rt_rows_kernel).  Through the scalar cache, as rt_stream_kernel reads the geometry, this kernel
@@ -662,6 +672,32 @@ __device__ __forceinline__ float lane_value(float v, int from)
 // slower (79 against 70 us for 1080p).
 // blockDim.x = a multiple of 64 (one tile per wave); grid = ceil(tiles / waves per workgroup);
 // dynamic LDS = rt_lite_lds_bytes().
+// Can a ray from o whose unit direction lies within the cone (axis ax, ay, az of length 1, half
+// angle theta < 90 degrees given by its sine and cosine) meet the sphere (c, r) as far as the
+// shader's floating-point test can tell?  false only when surely not.
+// The centre's distance from the cone's surface is at least p cos(theta) - z sin(theta), z = L.a the
+// depth along the axis and p = |L x a| the distance from it (L = c - o): the distance from a line
+// through the apex, which the apex itself is not nearer than.  The sphere is kept unless that exceeds
+// sqrt(r^2 + 2^-14 (o.o + c.c + r^2)) -- four times the sieve's margin, which already exceeds the
+// rounding of the shader's discriminant (sieve_pair) -- plus 10^-4 (|z| + p + r) for the rounding
+// here (a few ulp each).  Any NaN on the way compares false: kept.
+__device__ __forceinline__ bool tile_cone_keeps(float ox, float oy, float oz, float ax, float ay, float az,
+                                                float sin_t, float cos_t, float4 sphere)
+{
+    const float lx = sphere.x - ox, ly = sphere.y - oy, lz = sphere.z - oz;
+    const float z = __builtin_fmaf(lz, az, __builtin_fmaf(ly, ay, lx * ax));
+    const float qx = __builtin_fmaf(ly, az, -(lz * ay)), qy = __builtin_fmaf(lz, ax, -(lx * az)),
+                qz = __builtin_fmaf(lx, ay, -(ly * ax));
+    const float pd = __builtin_sqrtf(__builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx)));
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float cc = __builtin_fmaf(sphere.z, sphere.z, __builtin_fmaf(sphere.y, sphere.y, sphere.x * sphere.x));
+    const float rr = sphere.w * sphere.w;
+    const float reach = __builtin_sqrtf(__builtin_fmaf(6.103515625e-5f, oo + cc + rr, rr)) +
+                        1e-4f * (__builtin_fabsf(z) + pd + __builtin_fabsf(sphere.w));
+    const float away = __builtin_fmaf(pd, cos_t, -(z * sin_t));
+    return !(away > reach);
+}
+
 template <bool FUSED>
 __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
 {
@@ -704,13 +740,45 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     Path p;
     path_reset(p, P, d0x, d0y, d0z);
     bool alive = P.n_frames > 0;
+
+    // the spheres that the camera rays of this tile can meet: the cone around the ray of pixel (3, 3)
+    // that holds the 64 directions as they were computed (sine of the largest angle, a little more)
+    unsigned long long tile_spheres;
+    {
+        const float ax = lane_value(p.dx, 27), ay = lane_value(p.dy, 27), az = lane_value(p.dz, 27);
+        const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+        const float ux = ax * inv, uy = ay * inv, uz = az * inv;                     // the axis, length 1
+        const float dn = __builtin_amdgcn_rsqf(__builtin_fmaf(p.dz, p.dz, __builtin_fmaf(p.dy, p.dy, p.dx * p.dx)));
+        const float cx = __builtin_fmaf(p.dy, uz, -(p.dz * uy)), cy = __builtin_fmaf(p.dz, ux, -(p.dx * uz)),
+                    cz = __builtin_fmaf(p.dx, uy, -(p.dy * ux));
+        const float sine = __builtin_sqrtf(__builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx))) * dn;
+        const float along = __builtin_fmaf(p.dz, uz, __builtin_fmaf(p.dy, uy, p.dx * ux));
+        // |sine| as bits: NaN sorts above every number, so a direction that is not a number ends as "keep all"
+        const float sin_t = __builtin_fmaf(__uint_as_float(wave_max_u32(__float_as_uint(__builtin_fabsf(sine)))), 1.0001f, 1e-6f);
+        const float cos_t = __builtin_sqrtf(__builtin_fmaf(-sin_t, sin_t, 1.0f));   // NaN beyond 90 degrees
+        const bool narrow = __ballot(!(along > 0.0f)) == 0ull && sin_t < 0.5f;        // wave-uniform
+        const bool keep = !narrow || tile_cone_keeps(p.ox, p.oy, p.oz, ux, uy, uz, sin_t, cos_t, own);
+        tile_spheres = __ballot(keep && own_valid);
+    }
+    bool camera_pass = true;  // every live lane is on the camera ray of its pixel: the first pass only
+
     for (;;) {
         const unsigned long long alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
         int idx = -1;
-        if (__popcll(alive_mask) <= RT_LITE_TEAM_MAX) {  // wave-uniform
+        if (camera_pass) {  // wave-uniform
+            // ---- Trace() of the camera rays: the literal test of the tile's candidates, lowest index first
+            camera_pass = false;
+            for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
+                const int i = (int)__builtin_ctzll(todo);
+                bool far_root = false;
+                if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
+                const float4 g = smem[2 * i];
+                if (alive) test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
+            }
+        } else if (__popcll(alive_mask) <= RT_LITE_TEAM_MAX) {  // wave-uniform
             // ---- Trace() of the few rays left, one after the other, a sphere per lane
             for (unsigned long long todo = alive_mask; todo != 0ull; todo &= todo - 1ull) {
                 const int from = (int)__builtin_ctzll(todo);
