@@ -698,6 +698,41 @@ def test_ties_and_degenerate_spheres(rt, default_scene):
     assert 52 not in hits                         # radius 0 is never hit
 
 
+def test_small_spheres_across_tile_borders(rt):
+    """The lite kernel traces the camera rays of an 8x8 tile against the spheres that a cone around
+    them can meet.  64 small spheres scattered through the view, near and far, most of them cut by
+    tile borders, some a few pixels wide, one around the camera, one behind it: every limb pixel
+    must come out as the oracle's, under both float profiles and at two image sizes (narrow and
+    wide cones)."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, 64, 23)
+    sph = scene.spheres
+    cam = scene.camera["camera_position"][0].astype(np.float64)
+    fwd = scene.camera["camera_forward"][0].astype(np.float64)
+    right = scene.camera["camera_right"][0].astype(np.float64)
+    up = scene.camera["camera_up"][0].astype(np.float64)
+    rng = np.random.default_rng(5)
+    for i in range(64):
+        depth = rng.uniform(2.0, 80.0)
+        centre = cam + fwd * depth + right * rng.uniform(-1, 1) * depth + up * rng.uniform(-0.6, 0.6) * depth
+        sph[i]["center"] = centre.astype(np.float32)
+        sph[i]["radius"] = np.float32(depth * rng.choice([0.002, 0.01, 0.03, 0.1]))
+    sph[7]["center"] = cam.astype(np.float32)
+    sph[7]["radius"] = 1.5                       # around the camera
+    sph[9]["center"] = (cam - fwd * 5.0).astype(np.float32)
+    sph[9]["radius"] = 2.0                       # behind it
+    for w, h in ((512, 288), (48, 32)):
+        for profile in (0, 1):
+            acc, col, cnt = _render_gpu(rt, scene, w, h, profile=profile, kernel=rt.KERNEL_LITE, n_frames=2, depth=4,
+                                        sphere_count=64)
+            cacc, ccol, crays = _render_cpu(scene, w, h, profile=profile, n_frames=2, depth=4, sphere_count=64)
+            assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol), (w, h, profile)
+            assert cnt["rays"] == crays
+    # without the enclosing sphere most pixels see the small ones or the sky
+    acc, col, cnt = _render_gpu(rt, scene, 512, 288, profile=0, kernel=rt.KERNEL_LITE, n_frames=1, depth=4, sphere_count=7)
+    cacc, ccol, crays = _render_cpu(scene, 512, 288, profile=0, n_frames=1, depth=4, sphere_count=7)
+    assert np.array_equal(_bits(acc), _bits(cacc)) and cnt["rays"] == crays and crays > 512 * 288
+
+
 @pytest.mark.parametrize("size", [(8, 8), (7, 20), (20, 7), (9, 17), (1000, 24), (24, 1000), (8200, 16)])
 def test_odd_image_sizes(rt, default_scene, size):
     """Sizes that are not multiples of 8 (remainder pixels are never rendered), a single tile,
