@@ -382,9 +382,10 @@ def test_tile_rows_and_frame_stride_split(rt, default_scene, rtiow_scene, scene_
 
 
 def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
-    """From 16 frames per dispatch on, the lite kernel hands out its tiles heaviest first, by the ray
-    counts the previous dispatch of the same region left behind -- also after a resize and for a
-    band of tile rows.  The order must not show in the image."""
+    """The lite kernel hands out its tiles heaviest first, by the ray counts an earlier dispatch of
+    the same region left behind (sorted anew every 8 dispatches of 16 frames or more, every 128
+    shorter ones) -- also after a resize and for a band of tile rows.  The order must not show in
+    the image."""
     w, h = 200, 120
     ubo = default_scene.camera.copy()
     ubo["frameCount"][0] = 1
