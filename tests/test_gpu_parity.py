@@ -419,6 +419,27 @@ def test_repeated_many_frame_dispatches_of_a_small_scene(rt, default_scene):
         assert np.array_equal(_bits(band[24:88]), _bits(cband[24:88]))
 
 
+def test_many_single_frame_dispatches(rt, default_scene):
+    """One frame per dispatch, 131 times (the interactive loop): the tile order is sorted at the
+    second dispatch, serves 128 of them and is sorted again; the image must be the oracle's."""
+    w, h = 64, 40
+    ubo = default_scene.camera.copy()
+    with rt.Renderer(w, h) as r:
+        r.set_max_depth(6)
+        r.upload_spheres(default_scene.spheres)
+        total = 0
+        for k in range(131):
+            u = ubo.copy()
+            u["frameCount"][0] = 1 + k
+            r.set_uniforms(u)
+            r.dispatch(1)
+        total = r.counters()["rays"]
+        acc, col = r.read_accum(), r.read_color()
+    ubo["frameCount"][0] = 1
+    cacc, ccol, crays = O.render(ubo, default_scene.spheres, w, h, n_frames=131, max_depth=6, threads=8)
+    assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
+
+
 def test_span_order_of_large_scenes_does_not_show(rt):
     """From 1000 spheres and 4 M paths per dispatch on, the stream kernel (brute force, culled and
     bvh alike) takes its spans heaviest tile first, by the ray counts the previous dispatch left
