@@ -797,34 +797,34 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
                 }
             }
         } else {
-        // ---- Trace(): sieve + candidate walk (rt_stream_kernel has the commentary)
-        const SieveRay sr = sieve_ray(p, a, alive);
-        // read from LDS anew in every pass: the offset is hidden from the optimiser, which would
-        // otherwise keep the whole geometry in registers across passes
-        unsigned goff = 0;
-        asm volatile("" : "+v"(goff));
-        const v4f* geom = reinterpret_cast<const v4f*>(lgeom) + goff;
-        const uint32_t cand0 = ~sieve_chunk_partial<PGROUP>(geom, sr, groups0) & valid0;
-        uint32_t cand1 = 0u;
-        if (two) cand1 = ~sieve_chunk_partial<PGROUP>(geom + RT_CHUNK, sr, groups1) & valid1;
-        uint32_t cur = cand0;
-        int base = 0;
-        for (;;) {
-            if (cur == 0u && base == 0) {
-                cur = cand1;
-                base = RT_CHUNK;
+            // ---- Trace(): sieve + candidate walk (rt_stream_kernel has the commentary)
+            const SieveRay sr = sieve_ray(p, a, alive);
+            // read from LDS anew in every pass: the offset is hidden from the optimiser, which would
+            // otherwise keep the whole geometry in registers across passes
+            unsigned goff = 0;
+            asm volatile("" : "+v"(goff));
+            const v4f* geom = reinterpret_cast<const v4f*>(lgeom) + goff;
+            const uint32_t cand0 = ~sieve_chunk_partial<PGROUP>(geom, sr, groups0) & valid0;
+            uint32_t cand1 = 0u;
+            if (two) cand1 = ~sieve_chunk_partial<PGROUP>(geom + RT_CHUNK, sr, groups1) & valid1;
+            uint32_t cur = cand0;
+            int base = 0;
+            for (;;) {
+                if (cur == 0u && base == 0) {
+                    cur = cand1;
+                    base = RT_CHUNK;
+                }
+                if (__ballot(cur != 0u) == 0ull) break;
+                if (cur != 0u) {
+                    const int b = __clz(cur);
+                    cur &= ~(0x80000000u >> b);
+                    const int i = base + b;
+                    bool far_root = false;
+                    if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;  // wave-uniform branch
+                    const float4 g = smem[2 * i];
+                    test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
+                }
             }
-            if (__ballot(cur != 0u) == 0ull) break;
-            if (cur != 0u) {
-                const int b = __clz(cur);
-                cur &= ~(0x80000000u >> b);
-                const int i = base + b;
-                bool far_root = false;
-                if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;  // wave-uniform branch
-                const float4 g = smem[2 * i];
-                test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
-            }
-        }
         }
         // ---- shade; a lane whose path has ended goes straight on to its pixel's next frame
         if (alive) {
