@@ -650,20 +650,21 @@ __device__ __forceinline__ float lane_value(float v, int from)
 // dispatcher, no queues -- with the two things that matter kept from the stream kernel:
 //   - the sieve (packed-f32) and the candidate walk replace the literal loop over the spheres;
 //     the candidate masks of <= 2 chunks stay in registers;
-//   - a lane runs the frames of its pixel back to back on its own: when its path ends it starts
-//     the next frame at once instead of waiting for the slowest path of the tile, so over a
-//     dispatch of many frames the lanes of a wave stay busy (their sums of bounces even out).
+//   - the first pass of every frame is the camera rays of the tile's 64 pixels: one origin,
+//     directions within half a degree of one another.  Lane i tests sphere i against the cone that
+//     holds them all (tile_cone_keeps, once per tile), the ballot is the tile's candidate list, and
+//     every lane runs the literal test on just those, in index order and without divergence -- in
+//     place of 40 sieve tests and a walk as long as the busiest lane's.  Three rays in four are
+//     camera rays, so the lanes of a wave start every frame TOGETHER: a lane whose path has ended
+//     waits for the slowest path of the tile.  (Letting every lane go on to its pixel's next frame
+//     at once keeps the lanes busier but mixes camera rays with bounce rays in every pass, and
+//     then every pass pays for the sieve: measured 85 against 100 Grays/s at 1080p x 64 frames.)
 //   - when only a few lanes are left with a path (RT_LITE_TEAM_MAX; the mirror chains of up to
-//     max_depth bounces that a tile ends with, and that a dispatch of ONE frame ends with), a pass
-//     is no longer sieve + walk per lane -- some 400 dependent instructions for a lone ray -- but
-//     the literal test of every sphere at once: lane i holds sphere i, the ray is broadcast, every
-//     lane evaluates shader.comp:44-60 for its sphere and the wave takes the minimum t, lowest
-//     index among equal ones -- what the shader's strict `<` in index order keeps.
-//   - the first pass of a wave is the camera rays of its 64 pixels: one origin, directions within
-//     half a degree of one another.  Lane i tests sphere i against the cone that holds them all
-//     (tile_cone_keeps), the ballot is the tile's candidate list, and every lane runs the literal
-//     test on just those, in index order and without divergence -- in place of 40 sieve tests and
-//     a walk as long as the busiest lane's.  A dispatch of one frame is mostly this pass.
+//     max_depth bounces that a frame ends with), a pass is no longer sieve + walk per lane -- some
+//     400 dependent instructions for a lone ray -- but the literal test of every sphere at once:
+//     lane i holds sphere i, the ray is broadcast, every lane evaluates shader.comp:44-60 for its
+//     sphere and the wave takes the minimum t, lowest index among equal ones -- what the shader's
+//     strict `<` in index order keeps.
 // The workgroup first copies the sphere records and the sieve geometry into LDS and reads them
 // from there, the sieve in a loop over groups of sphere pairs that is not unrolled (see
 // rt_rows_kernel).  Through the scalar cache, as rt_stream_kernel reads the geometry, this kernel
@@ -760,11 +761,21 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         const bool keep = !narrow || tile_cone_keeps(p.ox, p.oy, p.oz, ux, uy, uz, sin_t, cos_t, own);
         tile_spheres = __ballot(keep && own_valid);
     }
-    bool camera_pass = true;  // every live lane is on the camera ray of its pixel: the first pass only
+    bool camera_pass = true;  // every live lane is on the camera ray of its pixel: the first pass of every frame
 
+    bool waiting = false;  // the lane's path of this frame has ended, the next frame's is set up
     for (;;) {
         const unsigned long long alive_mask = __ballot(alive);
-        if (alive_mask == 0ull) break;
+        if (alive_mask == 0ull) {
+            // the frame is done in every lane: on to the next one, all camera rays together again
+            if (__ballot(waiting) == 0ull) break;
+            if (waiting) {
+                alive = true;
+                waiting = false;
+            }
+            camera_pass = true;
+            continue;
+        }
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
         int idx = -1;
@@ -826,7 +837,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
                 }
             }
         }
-        // ---- shade; a lane whose path has ended goes straight on to its pixel's next frame
+        // ---- shade; a lane whose path has ended waits for the others with its next frame set up
         if (alive) {
             nrays++;
             if (path_bounce<FUSED, false>(p, P, idx, best, px, py, frame, nullptr, smem)) {
@@ -841,6 +852,8 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
                     frame = P.frame0 + (uint32_t)(j * P.frame_stride);
                     if (clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     path_reset(p, P, d0x, d0y, d0z);
+                    alive = false;
+                    waiting = true;
                 }
             }
         }
