@@ -92,6 +92,8 @@ struct rt_context {
     uint32_t* d_tile_order = nullptr;
     unsigned tile_cap = 0;       // tiles both arrays have room for
     unsigned cost_tiles = 0;     // tiles d_tile_cost describes (0: nothing yet), for the region below
+    float4* d_split = nullptr;   // lights of the tiles whose frames several waves share (use_frame_split)
+    size_t split_bytes = 0;
     unsigned order_tiles = 0;    // tiles d_tile_order orders (0: nothing yet), for the same region
     int order_uses = 0;          // dispatches that have used d_tile_order since it was sorted
     int cost_region[4] = {0, 0, 0, 0};  // tile_col0, tile_cols, tile_row0, tile_rows of that dispatch
@@ -755,6 +757,48 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
     c->cost_tiles = ntiles;  // valid once this dispatch has run (the stream is in order)
 }
 
+// Many frames of a small scene: the heavier half of the tiles of the order (as many as 1 GiB of lights
+// allows) are traced by several waves each, a run of frames per wave, and joined in frame order
+// afterwards (rt_lite_join_kernel).  A pixel between two mirrors bounces to the depth limit in every
+// frame, and all its frames in one lane are n_frames x max_depth passes one after the other: 1.2 ms of
+// a 1.45 ms dispatch at 1280x720 x 64 frames (depth 8), whatever else the chip does meanwhile.
+// Measured, runs per tile 2 / 4 / 8 (Grays/s): 640x360 x 64 frames 27 / 49 / 71 (unsplit 14), 1280x720 x 64
+// (depth 8) 89 / 99 / 97 (53), 1920x1080 x 64 112 / 107 / 104 (96), 3840x2160 x 16 114 / 108 / 97 -- the fewer
+// tiles a wave slot of the chip gets, the more runs; a quarter of the tiles split is no gain at 1080p, all
+// of them less than half.  Does nothing without an order or when the lights cannot be allocated.
+void use_frame_split(rt_context* c, RtParams& P)
+{
+    static const int share = env_int("RT_DEBUG_SPLIT_SHARE", 2);  // development knob: one tile in `share`; 0 = none
+    static const int ways_env = env_int("RT_DEBUG_SPLIT_WAYS", 0);  // development knob: 2, 4 or 8
+    P.split_tiles = 0;
+    P.split_ways = 0;
+    P.split_frames = 0;
+    P.split_lights = nullptr;
+    if (share <= 0 || P.tile_order == nullptr || P.n_frames < 16) return;
+    const unsigned ntiles = P.total_pixels / 64u;
+    const unsigned slots = 20u * (unsigned)c->cu_count;  // waves of this kernel that the chip holds at a time
+    int ways = 2 * ntiles < 3 * slots ? 8 : 2 * ntiles < 9 * slots ? 4 : 2;
+    if (ways_env == 2 || ways_env == 4 || ways_env == 8) ways = ways_env;
+    const int frames = (P.n_frames + ways - 1) / ways;
+    const size_t per_tile = (size_t)(ways - 1) * (size_t)frames * 64u * sizeof(float4);
+    const size_t tiles = std::min<size_t>(ntiles / (unsigned)share, ((size_t)1 << 30) / per_tile);
+    if (tiles == 0) return;
+    if (tiles * per_tile > c->split_bytes) {
+        if (c->d_split) (void)hipFree(c->d_split);
+        c->d_split = nullptr;
+        c->split_bytes = 0;
+        if (hipMalloc(&c->d_split, tiles * per_tile) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        c->split_bytes = tiles * per_tile;
+    }
+    P.split_tiles = (int)tiles;
+    P.split_ways = ways;
+    P.split_frames = frames;
+    P.split_lights = c->d_split;
+}
+
 int launch(rt_context* c, const RtParams& P_in, bool record)
 {
     RtParams P = P_in;
@@ -765,13 +809,13 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     const bool small = !record && P.n_pad <= 2 * RT_CHUNK;
     int which = c->kernel == RT_KERNEL_ROWS ? 2 : c->kernel == RT_KERNEL_LITE ? 1 : 0;
     if (c->kernel == RT_KERNEL_STREAM) {
-        // The lite kernel unless its units, tile x all frames, are too few and too long for the
-        // hardware dispatcher to balance: many frames of an image of less than about four tiles
-        // per wave slot (measured: 1280x720 x 64 frames 1.45 ms against 1.83 ms; 1920x1080 x 64
-        // frames 3.2 against 3.0 ms).
+        // The lite kernel.  (The rows kernel was the choice for many frames of a small image until
+        // the lite kernel began to share the frames of its heaviest tiles among several waves,
+        // use_frame_split: 1280x720 x 64 frames 0.79 ms against 1.45 ms, 640x360 x 64 frames 0.27
+        // against 0.54 ms.  Only the first dispatch of a region, which has no tile costs to go
+        // by yet, is slower than the rows kernel's on the smallest images.)
         const int env = small_scene_kernel();
-        const unsigned ntiles = P.total_pixels / 64u;
-        which = env >= 0 ? env : (P.n_frames >= 32 && ntiles < 80u * (unsigned)c->cu_count ? 2 : 1);
+        which = env >= 0 ? env : 1;
     }
     if (small && which == 2) return launch_rows(c, P, fused);
     if (small && which == 1) {
@@ -791,6 +835,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             // frame 61.7 -> 56.6-57.6 us (an order for 8 dispatches: 61.7 -> 61.9; for 32: 58.0).
             static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 1);  // development knob; < 0: never
             if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false, P.n_frames >= 16 ? 8 : 128);
+            use_frame_split(c, P);
             e = rt_launch_lite(P, fused, threads, c->stream);
         }
         if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
@@ -940,6 +985,7 @@ int rt_destroy(rt_context* c)
     if (c->d_boxes) (void)hipFree(c->d_boxes);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+    if (c->d_split) (void)hipFree(c->d_split);
     if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);

@@ -708,7 +708,18 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         smem[i] = reinterpret_cast<const float4*>(P.spheres)[i];
     for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
     __syncthreads();
-    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // The first split_tiles tiles of the order, the heaviest, go to split_ways waves each (below): wave
+    // `run` of a tile traces the frames [run, run + 1) * split_frames of the dispatch.  run < 0: all frames.
+    int run = -1;
+    const uint32_t ways = (uint32_t)P.split_ways;
+    const uint32_t split_slots = (uint32_t)P.split_tiles * ways;
+    if (slot < split_slots) {
+        run = (int)(slot % ways);
+        slot /= ways;
+    } else {
+        slot -= split_slots - (uint32_t)P.split_tiles;
+    }
     if (slot >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
     // heaviest tiles first, when the previous dispatch left their costs (rt_tile_order_kernel)
     const uint32_t tile = P.tile_order ? P.tile_order[slot] : slot;
@@ -718,8 +729,14 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     const uint32_t px = ((uint32_t)P.tile_col0 + tx) * 8 + (lane & 7u);
     const uint32_t py = ((uint32_t)P.tile_row0 + ty) * 8 + (lane >> 3);
     const size_t at = (size_t)py * P.width + px;
+    const int j_begin = run > 0 ? run * P.split_frames : 0;
+    const int j_end = run >= 0 ? min(P.n_frames, j_begin + P.split_frames) : P.n_frames;
+    // runs after the first leave their lights here, a frame after the other, for rt_lite_join_kernel
+    float4* lights = run > 0 ? P.split_lights + ((size_t)slot * (ways - 1u) + (size_t)(run - 1)) *
+                                                    (size_t)P.split_frames * 64u + lane
+                             : nullptr;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!clear_at(P, 0, P.frame0)) acc = P.accum[at];
+    if (run <= 0 && !clear_at(P, 0, P.frame0)) acc = P.accum[at];
     float d0x, d0y, d0z;
     primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
     const bool two = P.n_pad > RT_CHUNK;                   // one or two chunks of 32 spheres
@@ -735,12 +752,12 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     const float4 own = smem[2 * lane];
     const bool own_far = own_valid && P.materials != nullptr && P.materials[lane].x == 3.0f;
 
-    int j = 0;
-    uint32_t frame = P.frame0;
+    int j = j_begin;
+    uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
     unsigned nrays = 0;
     Path p;
     path_reset(p, P, d0x, d0y, d0z);
-    bool alive = P.n_frames > 0;
+    bool alive = j < j_end;
 
     // the spheres that the camera rays of this tile can meet: the cone around the ray of pixel (3, 3)
     // that holds the 64 directions as they were computed (sine of the largest angle, a little more)
@@ -841,12 +858,16 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         if (alive) {
             nrays++;
             if (path_bounce<FUSED, false>(p, P, idx, best, px, py, frame, nullptr, smem)) {
-                acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
-                acc.y = p.lg + acc.y;
-                acc.z = p.lb + acc.z;
-                acc.w = 1.0f + acc.w;
+                if (lights != nullptr) {
+                    lights[(size_t)(j - j_begin) * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);
+                } else {
+                    acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
+                    acc.y = p.lg + acc.y;
+                    acc.z = p.lb + acc.z;
+                    acc.w = 1.0f + acc.w;
+                }
                 j++;
-                if (j == P.n_frames) {
+                if (j == j_end) {
                     alive = false;
                 } else {
                     frame = P.frame0 + (uint32_t)(j * P.frame_stride);
@@ -858,9 +879,43 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
             }
         }
     }
-    store_pixel(P, px, py, acc);
+    if (run < 0) store_pixel(P, px, py, acc);
+    if (run == 0) P.accum[at] = acc;  // the sum so far; rt_lite_join_kernel adds the other runs' lights and resolves
     const unsigned long long wave_rays = add_rays(P, nrays, tile);
-    if (P.tile_cost != nullptr && lane == 0) P.tile_cost[tile] = (uint32_t)min(wave_rays, 0xffffffffull);
+    // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
+    if (P.tile_cost != nullptr && lane == 0 && run <= 0)
+        P.tile_cost[tile] = (uint32_t)min(wave_rays * (run == 0 ? ways : 1u), 0xffffffffull);
+}
+
+// The pixels of the tiles that rt_lite_kernel traced in split_ways runs of frames: the first run left
+// its sum in the accumulation image, the others the light of every frame; added here in frame order, as
+// one wave tracing all frames would have added them (float addition does not associate), then resolved.
+// Why split at all: a pixel between two mirrors bounces to the depth limit in every frame, and all its
+// frames in one lane are n_frames x max_depth passes one after the other -- 1.2 ms of a 1.45 ms dispatch
+// at 1280x720 x 64 frames, whatever else the chip does meanwhile.
+// One wave per split tile; blockDim.x = a multiple of 64.
+__global__ void __launch_bounds__(256) rt_lite_join_kernel(const RtParams P)
+{
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot >= (uint32_t)P.split_tiles) return;
+    const uint32_t tile = P.tile_order[slot];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
+    const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
+    const uint32_t px = ((uint32_t)P.tile_col0 + tx) * 8 + (lane & 7u);
+    const uint32_t py = ((uint32_t)P.tile_row0 + ty) * 8 + (lane >> 3);
+    float4 acc = P.accum[(size_t)py * P.width + px];
+    const float4* lights = P.split_lights + (size_t)slot * (size_t)(P.split_ways - 1) * (size_t)P.split_frames * 64u + lane;
+    for (int j = P.split_frames; j < P.n_frames; j++) {
+        const uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
+        if (clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 l = lights[(size_t)(j - P.split_frames) * 64u];  // run r, frame k of it: (r - 1) * split_frames + k
+        acc.x = l.x + acc.x;  // vec4(light, 1.0) + accumulated
+        acc.y = l.y + acc.y;
+        acc.z = l.z + acc.z;
+        acc.w = 1.0f + acc.w;
+    }
+    store_pixel(P, px, py, acc);
 }
 
 // Order of the tiles for the NEXT dispatch of rt_lite_kernel: descending cost (rays of the tile in
@@ -2693,7 +2748,9 @@ hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned 
 
 hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st)
 {
-    const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows;
+    // one wave per tile, split_ways for each of the first P.split_tiles tiles of the order
+    const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows +
+                           (P.split_tiles > 0 ? (unsigned)P.split_tiles * (unsigned)(P.split_ways - 1) : 0u);
     const unsigned per = (unsigned)threads / 64u;
     const dim3 grid((tiles + per - 1) / per), block(threads);
     const size_t lds = rt_lite_lds_bytes();
@@ -2701,7 +2758,12 @@ hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_
         hipLaunchKernelGGL((rt_lite_kernel<true>), grid, block, lds, st, P);
     else
         hipLaunchKernelGGL((rt_lite_kernel<false>), grid, block, lds, st, P);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && P.split_tiles > 0) {
+        hipLaunchKernelGGL(rt_lite_join_kernel, dim3((P.split_tiles + 3) / 4), dim3(256), 0, st, P);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 size_t rt_rows_lds_bytes(int threads)

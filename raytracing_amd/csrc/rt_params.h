@@ -22,6 +22,7 @@ constexpr int RT_SG_CHUNKS = 16;
 // closer to one another: measured at 3840x2160, 4096 spheres 15.3 -> 14.8 ms, 1000 spheres 11.1 -> 10.8 ms
 // (16 384 spheres, where the walk reads global memory: 26.7 -> 29.0 ms, so not there).
 constexpr int RT_SG_CHUNKS_WIDE = 32;
+
 // Largest sphere count whose geometry stream is staged in LDS (16 B per sphere).
 #ifndef RT_MAX_LDS
 #define RT_MAX_LDS 4096
@@ -134,6 +135,12 @@ struct RtParams {
     const uint32_t* tile_order;  // lite and stream kernels: k-th tile handed out -> tile of the dispatched region
                                  // (tiles in descending order of their cost in the previous dispatch), or null:
                                  // image order
+    int split_tiles;             // lite kernel, with tile_order: the first split_tiles tiles of the order are traced by
+                                 // split_ways waves each, a run of split_frames frames per wave (0: none)
+    int split_ways;              // 2, 4 or 8
+    int split_frames;            // ceil(n_frames / split_ways)
+    float4* split_lights;        // the light of every path of the runs after a tile's first:
+                                 // [tile of the order][run - 1][frame of the run][pixel of the tile]
     uint32_t* tile_cost;         // rays of each tile in this dispatch are left here (may be null): stored by the
                                  // lite kernel, added pixel by pixel by the stream kernel (zeroed before the launch)
     float4* accum;               // width*height rgba32f
