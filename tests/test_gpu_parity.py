@@ -440,6 +440,31 @@ def test_many_single_frame_dispatches(rt, default_scene):
     assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
 
 
+@pytest.mark.parametrize("size,frames,stride", [((96, 64), 19, 1), ((320, 200), 16, 3), ((640, 360), 33, 1)])
+def test_frames_of_heavy_tiles_shared_among_waves(rt, default_scene, size, frames, stride):
+    """From the second dispatch of 16 frames or more on, the lite kernel traces the frames of the heavier
+    half of its tiles in 2, 4 or 8 runs, a wave each (8 on images this small), parks the lights of the
+    later runs and adds them in frame order afterwards.  Frame counts that do not divide, a frame
+    stride, three dispatches in a row: accumulation image, colours and ray count must be the oracle's."""
+    w, h = size
+    ubo = default_scene.camera.copy()
+    with rt.Renderer(w, h) as r:
+        r.set_max_depth(8)
+        r.set_frame_schedule(stride, 0)
+        r.upload_spheres(default_scene.spheres)
+        for k in range(3):
+            u = ubo.copy()
+            u["frameCount"][0] = 1 + k * frames * stride
+            r.set_uniforms(u)
+            r.dispatch(frames)
+        total = r.counters()["rays"]
+        acc, col = r.read_accum(), r.read_color()
+    ubo["frameCount"][0] = 1
+    cacc, ccol, crays = O.render(ubo, default_scene.spheres, w, h, n_frames=3 * frames, frame_stride=stride, max_depth=8,
+                                 threads=8)
+    assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
+
+
 def test_span_order_of_large_scenes_does_not_show(rt):
     """From 1000 spheres and 4 M paths per dispatch on, the stream kernel (brute force, culled and
     bvh alike) takes its spans heaviest tile first, by the ray counts the previous dispatch left
