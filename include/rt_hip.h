@@ -48,7 +48,7 @@ enum {
 /* Which kernel runs a dispatch.  All give bit-identical images. */
 enum {
     RT_KERNEL_STREAM = 0, /* the default: brute force, the kernel chosen by sphere count -- up to 64
-                             traced spheres LITE or ROWS, from 65 to 65536 persistent waves (a lane
+                             traced spheres LITE, from 65 to 65536 persistent waves (a lane
                              whose path ends takes the next pixel) with the sieve on the matrix
                              cores, beyond that with the vector-ALU sieve                        */
     RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
@@ -64,12 +64,14 @@ enum {
                                   ALU keeps 2 instructions per test.  RT_KERNEL_STREAM picks it by itself from
                                   65 to 65536 traced spheres; this value forces it from 1 sphere on. */
     RT_KERNEL_LITE = 6,        /* at most 64 traced spheres (else STREAM): one wave per 8x8 tile as in TILE, no work
-                                  queues, with STREAM's sieve and candidate walk and every lane running its
-                                  pixel's frames back to back; RT_KERNEL_STREAM picks it for such scenes unless
-                                  ROWS fits the dispatch better. */
+                                  queues; the camera rays of a tile traced as a bundle, bounce rays with STREAM's
+                                  sieve and candidate walk; from the second dispatch of a region on the heaviest
+                                  tiles first, and with 16 and more frames per dispatch the frames of the heavier
+                                  tiles shared among 2 to 8 waves and joined in frame order (up to 1 GiB of device
+                                  memory, allocated on first use).  RT_KERNEL_STREAM picks it for such scenes. */
     RT_KERNEL_ROWS = 7,        /* at most 64 traced spheres (else STREAM): persistent waves whose lanes take work
                                   path by path, (pixel, frame), and add each pixel's frames in order through
-                                  LDS; RT_KERNEL_STREAM picks it for 32 and more frames of a small image. */
+                                  LDS. */
     RT_KERNEL_BVH = 8          /* STREAM_CULLED's sorted sphere list walked as a hierarchy by every lane on its
                                   own: blocks of 64 slots and their groups of 8 behind axis-aligned boxes, the
                                   spheres of a group behind the sieve (readme.md:38, "BVH implementation");
