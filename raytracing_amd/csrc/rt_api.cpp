@@ -92,6 +92,10 @@ struct rt_context {
     uint32_t* d_tile_order = nullptr;
     unsigned tile_cap = 0;       // tiles both arrays have room for
     unsigned cost_tiles = 0;     // tiles d_tile_cost describes (0: nothing yet), for the region below
+    uint32_t* d_tile_lists = nullptr;  // per tile, the spheres its camera rays can meet (use_tile_lists)
+    unsigned lists_cap = 0;            // tiles d_tile_lists has room for
+    bool lists_valid = false;          // d_tile_lists describes lists_key
+    float lists_key[12 + 8] = {0};     // camera, image size, region, sphere count and float profile of that
     float4* d_split = nullptr;   // lights of the tiles whose frames several waves share (use_frame_split)
     size_t split_bytes = 0;
     unsigned order_tiles = 0;    // tiles d_tile_order orders (0: nothing yet), for the same region
@@ -757,6 +761,47 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
     c->cost_tiles = ntiles;  // valid once this dispatch has run (the stream is in order)
 }
 
+// Brute-force stream kernel: the camera rays of a tile are traced against the list of spheres that any
+// of them can meet (rt_tile_lists_kernel; RtParams::tile_lists).  The lists depend on the camera, the
+// image, the region and the spheres; they are computed again only when one of those has changed
+// (a dispatch's worth of cone tests, tiles x spheres: ~0.1 ms for 129 600 tiles x 484 spheres).
+// Does nothing when the lists cannot be allocated.
+int use_tile_lists(rt_context* c, RtParams& P, bool fused)
+{
+    static const int on = env_int("RT_DEBUG_TILE_LISTS", 1);  // development knob: 0 = none
+    P.tile_lists = nullptr;
+    P.tile_list_max = 0;
+    if (!on) return RT_OK;
+    const unsigned ntiles = P.total_pixels / 64u;
+    if (ntiles > c->lists_cap) {
+        if (c->d_tile_lists) (void)hipFree(c->d_tile_lists);
+        c->d_tile_lists = nullptr;
+        c->lists_cap = 0;
+        c->lists_valid = false;
+        if (hipMalloc(&c->d_tile_lists, (size_t)ntiles * RT_TILE_LIST_WORDS * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return RT_OK;
+        }
+        c->lists_cap = ntiles;
+    }
+    float key[12 + 8];
+    memcpy(key, P.fwd, 12 * sizeof(float));  // fwd, right, up, pos: contiguous in RtParams
+    const int ints[8] = {P.width, P.height, P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows, P.sphere_count, fused ? 1 : 0};
+    memcpy(key + 12, ints, sizeof ints);
+    if (!c->lists_valid || memcmp(key, c->lists_key, sizeof key) != 0) {
+        c->lists_valid = false;
+        const hipError_t e = rt_launch_tile_lists(P, fused, c->d_tile_lists, c->stream);
+        if (e != hipSuccess) return fail(RT_E_HIP, "tile list kernel launch: %s", hipGetErrorString(e));
+        memcpy(c->lists_key, key, sizeof key);
+        c->lists_valid = true;
+    }
+    P.tile_lists = c->d_tile_lists;
+    // a list entry costs a literal test of every camera lane, ~60 instructions; a pass of the sieve
+    // about 4 per sphere: lists pay up to about a fifteenth of the sphere count
+    P.tile_list_max = std::min(RT_TILE_LIST_WORDS - 1, std::max(4, P.n_pad / 16));
+    return RT_OK;
+}
+
 // Many frames of a small scene: the heavier half of the tiles of the order (as many as 1 GiB of lights
 // allows) are traced by several waves each, a run of frames per wave, and joined in frame order
 // afterwards (rt_lite_join_kernel).  A pixel between two mirrors bounces to the depth limit in every
@@ -899,6 +944,10 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     if (!record && mode != 6 && lpt_min_spheres >= 0 && P.sphere_count >= lpt_min_spheres &&
         (long long)P.total_pixels * P.n_frames >= (1 << 22))
         use_tile_order(c, P, true, true);
+    if (!record && (mode == 0 || mode == 1 || mode == 3 || mode == 5)) {
+        const int rc = use_tile_lists(c, P, fused);
+        if (rc != RT_OK) return rc;
+    }
     hipError_t e = hipSuccess;
     if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
         c->fail_next_launch = false;
@@ -986,6 +1035,7 @@ int rt_destroy(rt_context* c)
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->d_split) (void)hipFree(c->d_split);
+    if (c->d_tile_lists) (void)hipFree(c->d_tile_lists);
     if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);
@@ -1022,6 +1072,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     if (cap > c->sphere_cap) {
         c->n_spheres = 0;  // until the new buffers are filled there is nothing to trace
         c->cull_count = -1;
+        c->lists_valid = false;
         c->have_materials = false;
         if (c->d_spheres) HIP_TRY(hipFree(c->d_spheres));
         if (c->d_geom) HIP_TRY(hipFree(c->d_geom));
@@ -1077,6 +1128,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     c->n_spheres = count;
     c->have_materials = false;  // materials belong to a sphere list: upload them again
     c->cull_count = -1;         // so does the sorted copy of the culled kernel
+    c->lists_valid = false;     // and the per-tile lists of the spheres that camera rays can meet
     host.resize(count);
     c->h_spheres.swap(host);
     return RT_OK;

@@ -956,6 +956,52 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&s_bin[cls(cost[i])], 1u)] = i;
 }
 
+// The spheres that the camera rays of each 8x8 tile can meet, for rt_stream_kernel: the cone test of
+// rt_lite_kernel (tile_cone_keeps) over the whole sphere list, 64 spheres at a time, a lane each.
+// lists: RT_TILE_LIST_WORDS words per tile of the dispatched region -- the count, then the indices
+// in ascending order; a count above RT_TILE_LIST_WORDS - 1 says "too many to list".
+// One wave per tile; blockDim.x = a multiple of 64.
+template <bool FUSED>
+__global__ void __launch_bounds__(256) rt_tile_lists_kernel(const RtParams P, uint32_t* lists)
+{
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
+    const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
+    const uint32_t px = ((uint32_t)P.tile_col0 + tx) * 8 + (lane & 7u);
+    const uint32_t py = ((uint32_t)P.tile_row0 + ty) * 8 + (lane >> 3);
+    float dx, dy, dz;
+    primary_direction<FUSED>(P, px, py, dx, dy, dz);
+    // the cone around the ray of pixel (3, 3) that holds the 64 directions as they were computed
+    const float ax = lane_value(dx, 27), ay = lane_value(dy, 27), az = lane_value(dz, 27);
+    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    const float ux = ax * inv, uy = ay * inv, uz = az * inv;
+    const float dn = __builtin_amdgcn_rsqf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+    const float cx = __builtin_fmaf(dy, uz, -(dz * uy)), cy = __builtin_fmaf(dz, ux, -(dx * uz)),
+                cz = __builtin_fmaf(dx, uy, -(dy * ux));
+    const float sine = __builtin_sqrtf(__builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx))) * dn;
+    const float along = __builtin_fmaf(dz, uz, __builtin_fmaf(dy, uy, dx * ux));
+    const float sin_t = __builtin_fmaf(__uint_as_float(wave_max_u32(__float_as_uint(__builtin_fabsf(sine)))), 1.0001f, 1e-6f);
+    const float cos_t = __builtin_sqrtf(__builtin_fmaf(-sin_t, sin_t, 1.0f));
+    const bool narrow = __ballot(!(along > 0.0f)) == 0ull && sin_t < 0.5f;  // wave-uniform
+    uint32_t* list = lists + (size_t)tile * RT_TILE_LIST_WORDS;
+    uint32_t total = 0;
+    for (int base = 0; base < P.sphere_count && total < (uint32_t)RT_TILE_LIST_WORDS; base += 64) {
+        const int i = base + (int)lane;
+        bool keep = false;
+        if (i < P.sphere_count) {
+            const float4 sphere = *reinterpret_cast<const float4*>(P.spheres + i);
+            keep = !narrow || tile_cone_keeps(P.pos[0], P.pos[1], P.pos[2], ux, uy, uz, sin_t, cos_t, sphere);
+        }
+        const unsigned long long kept = __ballot(keep);
+        const uint32_t at = total + mbcnt64(kept);
+        if (keep && at < (uint32_t)RT_TILE_LIST_WORDS - 1u) list[1u + at] = (uint32_t)i;
+        total += (uint32_t)__popcll(kept);
+    }
+    if (lane == 0) list[0] = total;  // above RT_TILE_LIST_WORDS - 1: not all of them are in the list
+}
+
 // ---------------------------------------------------------------- rows kernel
 
 // reg with its lane `lane_sel` replaced by `value` (both wave-uniform)
@@ -2058,6 +2104,34 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 // skips the groups no lane can touch.  3 = the sieve on the matrix cores.  4 = per-lane traversal
 // of the sorted list (trace_bvh).  5 = as 3 for scenes of more than RT_MAX_MFMA_SPHERES spheres: the
 // sphere-side operands stay in global memory.  6 = as 4 for scenes too large for LDS (trace_bvh_far).
+// shader.comp:96-125 for the ray that a lane of rt_stream_kernel has just traced, and what follows from
+// the end of a path.  A macro over the kernel's locals rather than a lambda: the closure cost the
+// kernel a private segment and a third of its scalar registers in spills.
+#define RT_STREAM_SHADE(best_, idx_)                                                                                        \
+    {                                                                                                                       \
+        nrays++;                                                                                                            \
+        if (path_bounce<FUSED, RECORD>(p, P, idx_, best_, px, py, frame, rec, reinterpret_cast<const float4*>(P.spheres))) { \
+            if constexpr (RECORD) record_light(P, px, py, j, p);                                                            \
+            acc.x = p.lr + acc.x; /* vec4(light, 1.0) + accumulated */                                                      \
+            acc.y = p.lg + acc.y;                                                                                           \
+            acc.z = p.lb + acc.z;                                                                                           \
+            acc.w = 1.0f + acc.w;                                                                                           \
+            j++;                                                                                                            \
+            if (j == P.n_frames) {                                                                                          \
+                if constexpr (!RECORD) {                                                                                    \
+                    store_pixel(P, px, py, acc);                                                                            \
+                    if (P.tile_cost != nullptr) /* the pixel's rays go to its tile's cost, for the next dispatch's order */ \
+                        atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +               \
+                                      ((px >> 3) - (uint32_t)P.tile_col0),                                                  \
+                                  nrays - pixel_rays0);                                                                     \
+                }                                                                                                           \
+                alive = false;                                                                                              \
+            } else {                                                                                                        \
+                start = true;                                                                                               \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+
 template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
 {
@@ -2223,6 +2297,46 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             start = false;
         }
 
+        // ---- Trace() of the camera rays, brute-force modes: the rays of a tile leave one point within
+        // half a degree of one another, and the spheres that any of them can meet are listed per tile
+        // (rt_tile_lists_kernel).  The lanes that hold a camera ray -- mostly of one tile, a span is a
+        // tile -- run the literal test on that list, in index order, are shaded, and take their first
+        // bounce through the sieve below in this same trip: a trip advances such a lane by two rays.
+        // A lane whose camera ray ended its path (sky) sits the sieve out.
+        if constexpr (!RECORD && !SORTED) {
+            if (P.tile_lists != nullptr) {  // wave-uniform
+                const bool camera = alive && p.bounce == 0;
+                unsigned long long todo = __ballot(camera);
+                if (todo != 0ull) {
+                    const uint32_t my_tile = ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +
+                                             ((px >> 3) - (uint32_t)P.tile_col0);
+                    const float a0 = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+                    float best0 = RT_FLT_MAX;
+                    int idx0 = -1;
+                    bool listed = false;
+                    while (todo != 0ull) {
+                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, (int)__builtin_ctzll(todo));
+                        const bool mine = camera && my_tile == t;
+                        todo &= ~__ballot(mine);
+                        const uint32_t* list = P.tile_lists + (size_t)t * RT_TILE_LIST_WORDS;
+                        const uint32_t n = list[0];
+                        if (n > (uint32_t)P.tile_list_max) continue;  // too many for a list: these lanes go through the sieve
+                        if (mine) listed = true;
+                        for (uint32_t e = 0; e < n; e++) {
+                            const int i = (int)list[1u + e];
+                            bool far_root = false;
+                            if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
+                            const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
+                            if (mine) test_sphere<FUSED>(p, a0, g.x, g.y, g.z, g.w, i, best0, idx0, far_root);
+                        }
+                    }
+                    if (listed) RT_STREAM_SHADE(best0, idx0)
+                }
+            }
+        }
+        const bool tracing = alive && !start;  // lanes with a ray for the sieve (all live ones, without the lists)
+        if (__ballot(tracing) == 0ull) continue;
+
 #ifdef RT_COUNT_PASSES
         npasses++;
 #endif
@@ -2231,10 +2345,10 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         float best = RT_FLT_MAX;
         int idx = -1;
         if constexpr (BVH) {
-            trace_bvh<FUSED>(p, a, alive, P, smem, radius, reinterpret_cast<const float4*>(frags), best, idx);
+            trace_bvh<FUSED>(p, a, tracing, P, smem, radius, reinterpret_cast<const float4*>(frags), best, idx);
             RT_MARK(t_walk)
         } else if constexpr (BVH_FAR) {
-            trace_bvh_far<FUSED>(p, a, alive, P, best, idx);
+            trace_bvh_far<FUSED>(p, a, tracing, P, best, idx);
             RT_MARK(t_walk)
         } else {
             SieveRay sr;
@@ -2242,7 +2356,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             if constexpr (MFMA)
                 mr = mfma_ray(p, a);
             else
-                sr = sieve_ray(p, a, alive);
+                sr = sieve_ray(p, a, tracing);
             for (int sg = 0; sg < nch; sg += sg_chunks) {
                 const int nsg = min(sg_chunks, nch - sg);
                 uint32_t summary = 0;
@@ -2250,7 +2364,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                 // this supergroup (4 groups of 8 spheres per chunk)
                 unsigned long long wneed = ~0ull;
                 if constexpr (CULL) {
-                    const SieveRay srb = sieve_ray(p, a, alive, RT_CULL_MARGIN_O);
+                    const SieveRay srb = sieve_ray(p, a, tracing, RT_CULL_MARGIN_O);
                     ConstGeomPtr bnd = (ConstGeomPtr)(const void*)(P.bounds) + sg * (RT_CHUNK / RT_CULL_GROUP);
                     uint32_t rej0, rej1 = 0xffffffffu;
                     if (nsg == RT_SG_CHUNKS) {
@@ -2274,15 +2388,15 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                 if constexpr (FAR_FRAGS) {
                     const v8bf* fr = reinterpret_cast<const v8bf*>(P.frags) + sg * 128;
                     summary = P.materials == nullptr
-                                  ? sieve_chunks_mfma_far<RT_MFMA_AHEAD, true>(fr, nsg, lane, mr, alive, sg + nsg == nch,
+                                  ? sieve_chunks_mfma_far<RT_MFMA_AHEAD, true>(fr, nsg, lane, mr, tracing, sg + nsg == nch,
                                                                                P.last_chunk_valid, wmask)
-                                  : sieve_chunks_mfma_far<RT_MFMA_AHEAD, false>(fr, nsg, lane, mr, alive, sg + nsg == nch,
+                                  : sieve_chunks_mfma_far<RT_MFMA_AHEAD, false>(fr, nsg, lane, mr, tracing, sg + nsg == nch,
                                                                                 P.last_chunk_valid, wmask);
                 } else if constexpr (MFMA) {
                     const v8bf* fr = reinterpret_cast<const v8bf*>(frags) + sg * 128;
                     summary = P.materials == nullptr
-                                  ? sieve_chunks_mfma<true>(fr, nsg, lane, mr, alive, sg + nsg == nch, P.last_chunk_valid, wmask)
-                                  : sieve_chunks_mfma<false>(fr, nsg, lane, mr, alive, sg + nsg == nch, P.last_chunk_valid, wmask);
+                                  ? sieve_chunks_mfma<true>(fr, nsg, lane, mr, tracing, sg + nsg == nch, P.last_chunk_valid, wmask)
+                                  : sieve_chunks_mfma<false>(fr, nsg, lane, mr, tracing, sg + nsg == nch, P.last_chunk_valid, wmask);
                 } else {
                     for (int c = 0; c < nsg; c++) {
                         constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
@@ -2353,29 +2467,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             if (idx >= 0) idx = P.perm[idx];  // slot of the sorted list -> the shader's sphere index
 
         // ---- shade
-        if (alive) {
-            nrays++;
-            if (path_bounce<FUSED, RECORD>(p, P, idx, best, px, py, frame, rec, reinterpret_cast<const float4*>(P.spheres))) {
-                if constexpr (RECORD) record_light(P, px, py, j, p);
-                acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
-                acc.y = p.lg + acc.y;
-                acc.z = p.lb + acc.z;
-                acc.w = 1.0f + acc.w;
-                j++;
-                if (j == P.n_frames) {
-                    if constexpr (!RECORD) {
-                        store_pixel(P, px, py, acc);
-                        if (P.tile_cost != nullptr)  // the pixel's rays go to its tile's cost, for the next dispatch's order
-                            atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +
-                                          ((px >> 3) - (uint32_t)P.tile_col0),
-                                      nrays - pixel_rays0);
-                    }
-                    alive = false;
-                } else {
-                    start = true;
-                }
-            }
-        }
+        if (tracing) RT_STREAM_SHADE(best, idx)
         RT_MARK(t_shade)
     }
 #ifdef RT_PHASE_TIMERS
@@ -2743,6 +2835,16 @@ void rt_bvh_step_counts(unsigned long long out[4])
 #endif
 
 size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4); }
+
+hipError_t rt_launch_tile_lists(const RtParams& P, bool fused, uint32_t* lists, hipStream_t st)
+{
+    const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows;
+    if (fused)
+        hipLaunchKernelGGL((rt_tile_lists_kernel<true>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, lists);
+    else
+        hipLaunchKernelGGL((rt_tile_lists_kernel<false>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, lists);
+    return hipGetLastError();
+}
 
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, hipStream_t st)
 {
