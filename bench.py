@@ -189,8 +189,13 @@ def pmc_record(key):
         return None
 
 
-def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key, sieve_mode):
-    """Algorithmic FP32 work and HBM bytes of the average launch against the two roofs."""
+def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key, sieve_mode, listed_share=0.0):
+    """Algorithmic FP32 work and HBM bytes of the average launch against the two roofs.
+    tests = rays x sphereCount; listed_share = the share of the rays that were camera rays traced against
+    the candidate list of their tile instead of the sphere list: their tests were never evaluated and are
+    left out of `achieved`."""
+    listed_tests = tests * listed_share
+    tests = tests - listed_tests
     launch_ms = kernel_ms / max(1, launches)
     achieved = tests / max(1, launches) * FLOP_PER_TEST / (launch_ms * 1e-3) / 1e12
     hbm = pixels_per_launch * BYTES_PER_PIXEL_DISPATCH / (launch_ms * 1e-3) / 1e9
@@ -204,6 +209,9 @@ def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key, sieve
         "unit": "TFLOP/s",
         "frac": achieved / PEAK_FP32_TFLOPS,
         "flop_per_test": FLOP_PER_TEST,
+        "tests_not_evaluated": {"share_of_rays_x_spheres": listed_share,
+                                "why": "camera rays are traced against the few spheres that a ray of their 8x8 tile can "
+                                       "meet (a cone test per tile); `achieved` counts the other rays' tests only"},
         "kernel_ms_per_launch": launch_ms,
         "launches": launches,
         "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBPS,
@@ -289,7 +297,7 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
 
     kernel_ms, launches = r.timed_total()
     cnt = r.counters()
-    stats = torch.tensor([elapsed, float(cnt["rays"])], dtype=torch.float64,
+    stats = torch.tensor([elapsed, float(cnt["rays"]), float(cnt["list_rays"])], dtype=torch.float64,
                          device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats.clone()
@@ -297,6 +305,7 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
     total_rays = float(stats[1])
+    total_listed = float(stats[2])
 
     if rank == 0:
         info = r.info()
@@ -323,7 +332,8 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
             },
             "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
             "roofline": roofline(args, cnt["sphere_tests"], launches, kernel_ms, (w // 8 * 8) * (h // 8 * 8),
-                                 f"{args.workload}_{args.kernel}_{args.profile}", r.sieve_mode()),
+                                 f"{args.workload}_{args.kernel}_{args.profile}", r.sieve_mode(),
+                                 listed_share=total_listed / max(1.0, total_rays)),
         }
         if args.cpu_seconds > 0 and world == 1:  # the CPU leg runs at N=1 only
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds)
@@ -432,7 +442,8 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
             "rays_per_path": cnt["rays"] / max(1, cnt["paths"]),
             # the slowest rank's kernel time over its launches; tests and pixels of that band
             "roofline": roofline(args, cnt["sphere_tests"], args.steps, kernel_ms, (w // 8 * 8) * band_rows,
-                                 f"interactive_{args.kernel}_{args.profile}", r.sieve_mode()),
+                                 f"interactive_{args.kernel}_{args.profile}", r.sieve_mode(),
+                                 listed_share=cnt["list_rays"] / max(1, cnt["rays"])),
         }
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds,

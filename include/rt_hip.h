@@ -96,6 +96,9 @@ typedef struct rt_counters {
     uint64_t rays;         /* Trace() calls (res/shaders/shader.comp:96) since the last reset */
     uint64_t sphere_tests; /* sum over dispatches of rays x that dispatch's sphereCount         */
     uint64_t paths;        /* pixel-frames rendered                                             */
+    uint64_t list_rays;    /* of `rays`: camera rays traced against the candidate list of their 8x8 tile
+                              (the spheres a camera ray of the tile can meet) instead of the whole
+                              sphere list -- their share of `sphere_tests` was never evaluated       */
 } rt_counters;
 
 /* ------------------------------------------------------------------ backend */

@@ -28,7 +28,7 @@ class Record(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("sphere_tests", C.c_uint64), ("paths", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("sphere_tests", C.c_uint64), ("paths", C.c_uint64), ("list_rays", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every function include/rt_hip.h declares.

@@ -1527,9 +1527,14 @@ int rt_get_counters(rt_context* c, rt_counters* out)
                 w[0] * 0.01 / nw, ~w[3] * 0.01, w[2] * 0.01, w[1] * 0.01 / nw, w[4] * 0.01);
     }
 #endif
+    unsigned long long list_rays = 0;
+#ifndef RT_PHASE_TIMERS
+    for (unsigned i = 0; i < RT_RAY_SLOTS; i++) list_rays += slots[i * RT_RAY_SLOT_STRIDE + 4];
+#endif
     out->rays = rays;
     out->sphere_tests = tests;
     out->paths = c->paths;
+    out->list_rays = list_rays;
     return RT_OK;
 }
 

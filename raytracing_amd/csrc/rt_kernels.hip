@@ -388,16 +388,25 @@ __device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
 // the sphere count of this dispatch (word 2), into one of RT_RAY_SLOTS slots a cache line apart
 // (the host adds them up): the waves of a launch finish together, and on a single address their
 // additions would complete one after the other.
-__device__ __forceinline__ unsigned long long add_rays(const RtParams& P, unsigned nrays, unsigned slot)
+// nlist: those of the rays that were traced against a tile's candidate list instead of the whole
+// sphere list (word 4 of the slot; not in the builds that stamp phase times into words 3..7).
+__device__ __forceinline__ unsigned long long add_rays(const RtParams& P, unsigned nrays, unsigned slot, unsigned nlist = 0)
 {
-    unsigned long long v = nrays;
+    unsigned long long v = nrays, w = nlist;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_down(v, off, 64);
+        w += __shfl_down(w, off, 64);
+    }
     v = __shfl(v, 0, 64);
+    w = __shfl(w, 0, 64);
     const unsigned lane = threadIdx.x & 63;
     if ((lane == 0 || lane == 2) && v != 0)
         atomicAdd(P.rays + (slot % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + lane,
                   lane == 0 ? v : v * (unsigned long long)P.sphere_count);
+#ifndef RT_PHASE_TIMERS
+    if (lane == 4 && w != 0) atomicAdd(P.rays + (slot % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 4, w);
+#endif
     return v;  // the wave's rays
 }
 
@@ -758,7 +767,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
 
     int j = j_begin;
     uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
-    unsigned nrays = 0;
+    unsigned nrays = 0, nlist = 0;
     Path p;
     path_reset(p, P, d0x, d0y, d0z);
     bool alive = j < j_end;
@@ -803,6 +812,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         if (camera_pass) {  // wave-uniform
             // ---- Trace() of the camera rays: the literal test of the tile's candidates, lowest index first
             camera_pass = false;
+            if (alive) nlist++;
             for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
                 const int i = (int)__builtin_ctzll(todo);
                 bool far_root = false;
@@ -885,7 +895,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     }
     if (run < 0) store_pixel(P, px, py, acc);
     if (run == 0) P.accum[at] = acc;  // the sum so far; rt_lite_join_kernel adds the other runs' lights and resolves
-    const unsigned long long wave_rays = add_rays(P, nrays, tile);
+    const unsigned long long wave_rays = add_rays(P, nrays, tile, nlist);
     // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
     if (P.tile_cost != nullptr && lane == 0 && run <= 0)
         P.tile_cost[tile] = (uint32_t)min(wave_rays * (run == 0 ? ways : 1u), 0xffffffffull);
@@ -2207,7 +2217,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     uint32_t px = 0, py = 0, frame = 0;
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned nrays = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
+    unsigned nrays = 0, nlist = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
 #ifdef RT_COUNT_PASSES
     unsigned npasses = 0;  // experiment: passes over the sphere list, added to the word after the ray counter
 #endif
@@ -2330,7 +2340,10 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                             if (mine) test_sphere<FUSED>(p, a0, g.x, g.y, g.z, g.w, i, best0, idx0, far_root);
                         }
                     }
-                    if (listed) RT_STREAM_SHADE(best0, idx0)
+                    if (listed) {
+                        nlist++;
+                        RT_STREAM_SHADE(best0, idx0)
+                    }
                 }
             }
         }
@@ -2492,7 +2505,7 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         atomicAdd(slot + 13, 1ull);
     }
 #endif
-    if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave);
+    if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave, nlist);
 #ifdef RT_COUNT_PASSES
     if (lane == 0)
         atomicAdd(P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 1,

@@ -190,7 +190,7 @@ class Renderer:
     def counters(self) -> dict:
         c = N.Counters()
         N.check(N.lib().rt_get_counters(self._h, C.byref(c)))
-        return {"rays": int(c.rays), "sphere_tests": int(c.sphere_tests), "paths": int(c.paths)}
+        return {"rays": int(c.rays), "sphere_tests": int(c.sphere_tests), "paths": int(c.paths), "list_rays": int(c.list_rays)}
 
     def reset_counters(self) -> None:
         N.check(N.lib().rt_reset_counters(self._h))

@@ -465,6 +465,61 @@ def test_frames_of_heavy_tiles_shared_among_waves(rt, default_scene, size, frame
     assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
 
 
+def test_tile_lists_follow_camera_scene_and_size(rt, rtiow_scene):
+    """The stream kernel traces camera rays against per-tile lists of the spheres they can meet, computed
+    by a cone test and kept while camera, image and spheres stay.  One context through a still camera
+    (lists reused), a moved and a turned camera, a camera inside the scene, other spheres, another
+    image size and a band of tile rows: every image must be the oracle's, and the lists must have
+    been used (counter)."""
+    scene = rtiow_scene
+    w, h = 192, 112
+    cams = []
+    base = scene.camera.copy()
+    base["frameCount"][0] = 1
+    cams.append(base.copy())
+    cams.append(base.copy())                                   # the same again: lists reused
+    moved = base.copy()
+    moved["camera_position"][0] += np.float32([1.5, 0.7, -2.0])
+    cams.append(moved)
+    turned = moved.copy()                                        # look along -right instead
+    turned["camera_forward"][0] = -moved["camera_right"][0]
+    turned["camera_right"][0] = moved["camera_forward"][0]
+    cams.append(turned)
+    inside = base.copy()
+    inside["camera_position"][0] = np.float32([0.3, 0.6, 0.4])   # among the small spheres
+    cams.append(inside)
+    with rt.Renderer(w, h) as r:
+        r.set_max_depth(6)
+        r.upload_spheres(scene.spheres)
+        for k, ubo in enumerate(cams):
+            r.reset_counters()
+            r.set_uniforms(ubo)
+            r.dispatch(2)
+            cnt = r.counters()
+            cacc, ccol, crays = O.render(ubo, scene.spheres, w, h, n_frames=2, max_depth=6, threads=8)
+            assert np.array_equal(_bits(r.read_accum()), _bits(cacc)) and np.array_equal(r.read_color(), ccol), k
+            assert cnt["rays"] == crays and 0 < cnt["list_rays"] <= cnt["paths"], (k, cnt)
+        other = scene.spheres.copy()
+        other["center"][3:200] += np.float32([0.0, 0.35, 0.0])    # most small spheres lifted off the ground
+        r.upload_spheres(other)
+        r.set_uniforms(base)
+        r.dispatch(2)
+        cacc, ccol, _ = O.render(base, other, w, h, n_frames=2, max_depth=6, threads=8)
+        assert np.array_equal(_bits(r.read_accum()), _bits(cacc)) and np.array_equal(r.read_color(), ccol)
+        r.resize(96, 160)
+        r.set_uniforms(base)
+        r.dispatch(2)
+        cacc, ccol, _ = O.render(base, other, 96, 160, n_frames=2, max_depth=6, threads=8)
+        assert np.array_equal(_bits(r.read_accum()), _bits(cacc)) and np.array_equal(r.read_color(), ccol)
+        r.set_tile_rows(4, 13)
+        u = base.copy()
+        u["frameCount"][0] = 3
+        r.set_uniforms(u)
+        r.dispatch(1)
+        cband, _, _ = O.render(u, other, 96, 160, n_frames=1, max_depth=6, rows=(4, 13), accum=cacc.copy(), threads=8)
+        assert np.array_equal(_bits(r.read_accum()[32:104]), _bits(cband[32:104]))
+
+
 def test_span_order_of_large_scenes_does_not_show(rt):
     """From 1000 spheres and 4 M paths per dispatch on, the stream kernel (brute force, culled and
     bvh alike) takes its spans heaviest tile first, by the ray counts the previous dispatch left
