@@ -684,7 +684,7 @@ def test_counters_follow_the_sphere_count_of_each_dispatch(rt, default_scene, ke
         cnt = r.counters()
         assert cnt["sphere_tests"] == expect and cnt["paths"] == 4 * 2 * 128 * 72
         r.reset_counters()
-        assert r.counters() == {"rays": 0, "sphere_tests": 0, "paths": 0}
+        assert r.counters() == {"rays": 0, "sphere_tests": 0, "paths": 0, "list_rays": 0}
 
 
 # ---------------------------------------------------------------- full-size properties
