@@ -50,7 +50,9 @@ enum {
     RT_KERNEL_STREAM = 0, /* the default: brute force, the kernel chosen by sphere count -- up to 64
                              traced spheres LITE, from 65 to 65536 persistent waves (a lane
                              whose path ends takes the next pixel) with the sieve on the matrix
-                             cores, beyond that with the vector-ALU sieve                        */
+                             cores, beyond that with the vector-ALU sieve; camera rays are
+                             traced against a per-tile list of the spheres they can meet
+                             (128 B of device memory per 8x8 tile, rt_counters.list_rays)      */
     RT_KERNEL_TILE = 1,   /* one wave per 8x8 tile, one lane per pixel (the shader's mapping) */
     RT_KERNEL_STREAM_SGPR = 2, /* STREAM, sieve geometry read through the scalar cache (SGPRs) */
     RT_KERNEL_STREAM_LDS = 3,  /* STREAM, sieve geometry read from the LDS copy                */
