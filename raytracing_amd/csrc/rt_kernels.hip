@@ -2307,13 +2307,13 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             start = false;
         }
 
-        // ---- Trace() of the camera rays, brute-force modes: the rays of a tile leave one point within
+        // ---- Trace() of the camera rays: the rays of a tile leave one point within
         // half a degree of one another, and the spheres that any of them can meet are listed per tile
         // (rt_tile_lists_kernel).  The lanes that hold a camera ray -- mostly of one tile, a span is a
         // tile -- run the literal test on that list, in index order, are shaded, and take their first
         // bounce through the sieve below in this same trip: a trip advances such a lane by two rays.
         // A lane whose camera ray ended its path (sky) sits the sieve out.
-        if constexpr (!RECORD && !SORTED) {
+        if constexpr (!RECORD && !CULL) {
             if (P.tile_lists != nullptr) {  // wave-uniform
                 const bool camera = alive && p.bounce == 0;
                 unsigned long long todo = __ballot(camera);
