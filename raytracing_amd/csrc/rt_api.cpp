@@ -96,6 +96,7 @@ struct rt_context {
     unsigned lists_cap = 0;            // tiles d_tile_lists has room for
     bool lists_valid = false;          // d_tile_lists describes lists_key
     float lists_key[12 + 8] = {0};     // camera, image size, region, sphere count and float profile of that
+    unsigned long long lite_paths = 0;  // paths of the lite kernel's dispatches since the counters were reset
     float4* d_split = nullptr;   // lights of the tiles whose frames several waves share (use_frame_split)
     size_t split_bytes = 0;
     unsigned order_tiles = 0;    // tiles d_tile_order orders (0: nothing yet), for the same region
@@ -884,6 +885,7 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             e = rt_launch_lite(P, fused, threads, c->stream);
         }
         if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
+        c->lite_paths += (unsigned long long)P.total_pixels * (unsigned)P.n_frames;  // camera rays traced against tile lists
         c->last_mode = 4;
         return RT_OK;
     }
@@ -1534,6 +1536,7 @@ int rt_get_counters(rt_context* c, rt_counters* out)
 #ifndef RT_PHASE_TIMERS
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) list_rays += slots[i * RT_RAY_SLOT_STRIDE + 4];
 #endif
+    list_rays += c->lite_paths;  // the lite kernel: every camera ray, and an atomic per wave would cost it 6 %
     out->rays = rays;
     out->sphere_tests = tests;
     out->paths = c->paths;
@@ -1547,6 +1550,7 @@ int rt_reset_counters(rt_context* c)
     RT_ON_DEVICE(c);
     HIP_TRY(hipMemsetAsync(c->d_rays, 0, RT_RAY_BYTES, c->stream));
     c->paths = 0;
+    c->lite_paths = 0;
     return RT_OK;
 }
 

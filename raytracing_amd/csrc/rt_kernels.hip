@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
 
     int j = j_begin;
     uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
-    unsigned nrays = 0, nlist = 0;
+    unsigned nrays = 0;
     Path p;
     path_reset(p, P, d0x, d0y, d0z);
     bool alive = j < j_end;
@@ -812,7 +812,6 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         if (camera_pass) {  // wave-uniform
             // ---- Trace() of the camera rays: the literal test of the tile's candidates, lowest index first
             camera_pass = false;
-            if (alive) nlist++;
             for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
                 const int i = (int)__builtin_ctzll(todo);
                 bool far_root = false;
@@ -895,7 +894,8 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     }
     if (run < 0) store_pixel(P, px, py, acc);
     if (run == 0) P.accum[at] = acc;  // the sum so far; rt_lite_join_kernel adds the other runs' lights and resolves
-    const unsigned long long wave_rays = add_rays(P, nrays, tile, nlist);
+    // (every camera ray of this kernel is traced against its tile's list: the host counts them, a path each)
+    const unsigned long long wave_rays = add_rays(P, nrays, tile);
     // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
     if (P.tile_cost != nullptr && lane == 0 && run <= 0)
         P.tile_cost[tile] = (uint32_t)min(wave_rays * (run == 0 ? ways : 1u), 0xffffffffull);
