@@ -558,15 +558,23 @@ void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const R
 {
     const bool far = P.frags != nullptr && P.n_pad > RT_MAX_MFMA_SPHERES;  // matrix-core sieve, operands left in global memory
     const bool mfma = P.frags != nullptr && !far;  // the operand fragments are staged in LDS too: larger workgroups share them
-    // matrix-core sieve: two waves per SIMD saturate it (measured: 8 waves per CU = 12 = 16); 256-thread
-    // workgroups while two of them fit in LDS, else one of 512
-    const int t_mfma = rt_stream_lds_bytes(P.n_lds, 256, true, 0, P.sg_wide) * 2 <= kLdsPerCu ? 256 : 512;
+    // matrix-core sieve with its operands in LDS: one workgroup of 768 threads per CU, three waves per SIMD
+    // sharing one copy of the operands (measured at 484 spheres, since camera rays go by tile lists and the
+    // kernel no longer fills the issue port: 19.7-20.3 Grays/s against 18.7-19.3 for two workgroups of 256);
+    // 512 or 256 threads when 768 do not fit in LDS
+    static const int t_env = [] {  // development knob
+        const char* e = getenv("RT_DEBUG_MFMA_THREADS");
+        return e ? atoi(e) : RT_MFMA_MAX_THREADS;
+    }();
+    int t_mfma = std::max(256, std::min(RT_MFMA_MAX_THREADS, t_env / 256 * 256));
+    while (t_mfma > 256 && rt_stream_lds_bytes(P.n_lds, t_mfma, true, 0, P.sg_wide) > kLdsPerCu) t_mfma -= 256;
+    if (t_mfma == 256 && rt_stream_lds_bytes(P.n_lds, 256, true, 0, P.sg_wide) * 2 > kLdsPerCu) t_mfma = 512;
     int t = want_threads > 0 ? want_threads : (mfma ? t_mfma : P.n_lds <= 1024 ? 256 : RT_STREAM_MAX_THREADS);
     t = std::max(64, std::min(mfma ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS, t / 64 * 64));
     const size_t lds = rt_stream_lds_bytes(P.n_lds, t, mfma, 0, P.sg_wide);
     const unsigned long long paths = (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
     int waves_per_cu = paths < 16ull * 64 * 12 * (unsigned)cu_count ? 8 : 12;
-    if (mfma) waves_per_cu = 8;
+    if (mfma) waves_per_cu = t == 768 ? 12 : 8;
     int per_cu = std::min<int>(std::max(1, waves_per_cu / (t / 64)), (int)(kLdsPerCu / std::max<size_t>(lds, 1)));
     per_cu = std::max(1, per_cu);
     int b = want_blocks > 0 ? want_blocks : cu_count * per_cu;
