@@ -465,6 +465,30 @@ def test_frames_of_heavy_tiles_shared_among_waves(rt, default_scene, size, frame
     assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol) and total == crays
 
 
+@pytest.mark.parametrize("clear", [1, 2])
+def test_shared_frames_under_the_other_clear_modes(rt, default_scene, clear):
+    """The sample split over GPUs runs with clear mode FIRST (a dispatch starts from zero) and NEVER (it
+    adds to what is there), frame stride = number of GPUs: three dispatches of 20 frames, the later
+    ones with the frames of the heavier tiles shared among waves, against the oracle run the same way."""
+    w, h, frames, stride = 160, 96, 20, 4
+    ubo = default_scene.camera.copy()
+    cacc = np.zeros((h, w, 4), np.float32)
+    with rt.Renderer(w, h) as r:
+        r.set_max_depth(8)
+        r.upload_spheres(default_scene.spheres)
+        for k in range(3):
+            mode = 1 if k == 0 else clear  # the first dispatch starts from zero either way
+            r.set_frame_schedule(stride, mode)
+            u = ubo.copy()
+            u["frameCount"][0] = 3 + k * frames * stride
+            r.set_uniforms(u)
+            r.dispatch(frames)
+            cacc, ccol, _ = O.render(u, default_scene.spheres, w, h, n_frames=frames, frame_stride=stride, max_depth=8,
+                                     clear_mode=mode, accum=cacc.copy(), threads=8)
+            assert np.array_equal(_bits(r.read_accum()), _bits(cacc)), k
+            assert np.array_equal(r.read_color(), ccol), k
+
+
 def test_tile_lists_follow_camera_scene_and_size(rt, rtiow_scene):
     """The stream kernel traces camera rays against per-tile lists of the spheres they can meet, computed
     by a cone test and kept while camera, image and spheres stay.  One context through a still camera
