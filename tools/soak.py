@@ -24,6 +24,8 @@ with rt.Renderer(64, 64) as r:
     r.set_max_depth(10)
     cur_scene = None
     for it in range(iters):
+        if it % 50 == 0:
+            print(f"iteration {it}, {time.time() - t0:.0f} s", flush=True)
         si = int(rng.integers(len(scenes)))
         w, h = sizes[int(rng.integers(len(sizes)))]
         frames = int(rng.choice([1, 2, 3, 33, 64]))  # 32 frames and more: the rows kernel on small scenes
