@@ -98,9 +98,11 @@ typedef struct rt_counters {
     uint64_t rays;         /* Trace() calls (res/shaders/shader.comp:96) since the last reset */
     uint64_t sphere_tests; /* sum over dispatches of rays x that dispatch's sphereCount         */
     uint64_t paths;        /* pixel-frames rendered                                             */
-    uint64_t list_rays;    /* of `rays`: camera rays traced against the candidate list of their 8x8 tile
-                              (the spheres a camera ray of the tile can meet) instead of the whole
-                              sphere list -- their share of `sphere_tests` was never evaluated       */
+    uint64_t list_rays;    /* of `rays`: camera rays that were not traced against the whole sphere list --
+                              traced against the candidate list of their 8x8 tile (the spheres a camera
+                              ray of the tile can meet), or served by the hit their pixel's camera ray
+                              found in an earlier frame of the dispatch (RT_OPTION_CAMERA_SHORTCUTS);
+                              their share of `sphere_tests` was never evaluated                      */
 } rt_counters;
 
 /* ------------------------------------------------------------------ backend */
@@ -145,6 +147,18 @@ int rt_set_max_depth(rt_context* ctx, int max_depth);
    reference counterpart: the shader source leaves the first open and has one kernel. */
 int rt_set_profile(rt_context* ctx, int profile);
 int rt_set_kernel(rt_context* ctx, int kernel);
+
+/* Options of a context.  No reference counterpart: the shader's Trace() always walks the whole
+   sphere list (res/shaders/shader.comp:42).
+     RT_OPTION_CAMERA_SHORTCUTS (default 1): a pixel's camera ray is the same ray in every frame
+       (origin and direction depend on camera and pixel only, shader.comp:73-90), and the camera rays
+       of an 8x8 tile leave one point within half a degree of one another.  With 1 the default kernels
+       (RT_KERNEL_STREAM and what it picks) trace camera rays against a per-tile list of the spheres
+       that any of them can meet, and find a pixel's camera hit once per dispatch for all its frames;
+       rt_counters.list_rays counts the Trace() calls so served.  With 0 every Trace() call of every
+       frame evaluates the whole sphere list.  Same bits either way. */
+enum { RT_OPTION_CAMERA_SHORTCUTS = 0 };
+int rt_set_option(rt_context* ctx, int option, int value);
 
 /* Rows [row0,row1) of 8x8 tiles this context renders (screen-tile split across
    GPUs); row1 <= 0 restores the whole image.  The reference always dispatches

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rt_set_max_depth": (C.c_int, [_P, C.c_int]),
     "rt_set_profile": (C.c_int, [_P, C.c_int]),
     "rt_set_kernel": (C.c_int, [_P, C.c_int]),
+    "rt_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_set_tile_rows": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_set_frame_schedule": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_dispatch": (C.c_int, [_P]),

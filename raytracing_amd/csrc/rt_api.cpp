@@ -92,10 +92,10 @@ struct rt_context {
     uint32_t* d_tile_order = nullptr;
     unsigned tile_cap = 0;       // tiles both arrays have room for
     unsigned cost_tiles = 0;     // tiles d_tile_cost describes (0: nothing yet), for the region below
-    uint32_t* d_tile_lists = nullptr;  // per tile, the spheres its camera rays can meet (use_tile_lists)
-    unsigned lists_cap = 0;            // tiles d_tile_lists has room for
-    bool lists_valid = false;          // d_tile_lists describes lists_key
-    float lists_key[12 + 8] = {0};     // camera, image size, region, sphere count and float profile of that
+    uint2* d_cam_hits = nullptr;       // per pixel, the nearest hit of its camera ray (use_camera_hits)
+    unsigned hits_cap = 0;             // tiles d_cam_hits has room for
+    bool hits_valid = false;           // d_cam_hits describes hits_key
+    float hits_key[12 + 8] = {0};      // camera, image size, region, sphere count and float profile of that
     unsigned long long lite_paths = 0;  // paths of the lite kernel's dispatches since the counters were reset
     float4* d_split = nullptr;   // lights of the tiles whose frames several waves share (use_frame_split)
     size_t split_bytes = 0;
@@ -122,6 +122,7 @@ struct rt_context {
     int frame_stride = 1;
     int clear_mode = RT_CLEAR_REFERENCE;
     int blocks = 0, threads = 0;  // 0 = automatic
+    bool camera_shortcuts = true;   // RT_OPTION_CAMERA_SHORTCUTS
     bool fail_next_launch = false;  // rt_debug_fail_next_launch
     // rt_dispatch_frames_timed: event pairs around dispatches not yet read by rt_timed_total
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_pending, timed_free;
@@ -770,44 +771,39 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
     c->cost_tiles = ntiles;  // valid once this dispatch has run (the stream is in order)
 }
 
-// Brute-force stream kernel: the camera rays of a tile are traced against the list of spheres that any
-// of them can meet (rt_tile_lists_kernel; RtParams::tile_lists).  The lists depend on the camera, the
-// image, the region and the spheres; they are computed again only when one of those has changed
-// (a dispatch's worth of cone tests, tiles x spheres: ~0.1 ms for 129 600 tiles x 484 spheres).
-// Does nothing when the lists cannot be allocated.
-int use_tile_lists(rt_context* c, RtParams& P, bool fused)
+// Stream kernel: the nearest hit of every pixel's camera ray, found once (rt_camera_hits_kernel;
+// RtParams::cam_hits) and used by every frame of every dispatch until the camera, the image, the
+// region, the spheres, the materials or the float profile change (~0.15 ms for 3840x2160 and 484
+// spheres; 8 bytes of device memory per pixel of the region).  Does nothing when RT_OPTION_CAMERA_SHORTCUTS
+// is off or the buffer cannot be allocated.
+int use_camera_hits(rt_context* c, RtParams& P, bool fused)
 {
-    static const int on = env_int("RT_DEBUG_TILE_LISTS", 1);  // development knob: 0 = none
-    P.tile_lists = nullptr;
-    P.tile_list_max = 0;
-    if (!on) return RT_OK;
+    P.cam_hits = nullptr;
+    if (!c->camera_shortcuts) return RT_OK;
     const unsigned ntiles = P.total_pixels / 64u;
-    if (ntiles > c->lists_cap) {
-        if (c->d_tile_lists) (void)hipFree(c->d_tile_lists);
-        c->d_tile_lists = nullptr;
-        c->lists_cap = 0;
-        c->lists_valid = false;
-        if (hipMalloc(&c->d_tile_lists, (size_t)ntiles * RT_TILE_LIST_WORDS * 4) != hipSuccess) {
+    if (ntiles > c->hits_cap) {
+        if (c->d_cam_hits) (void)hipFree(c->d_cam_hits);
+        c->d_cam_hits = nullptr;
+        c->hits_cap = 0;
+        c->hits_valid = false;
+        if (hipMalloc(&c->d_cam_hits, (size_t)ntiles * 64u * sizeof(uint2)) != hipSuccess) {
             (void)hipGetLastError();
             return RT_OK;
         }
-        c->lists_cap = ntiles;
+        c->hits_cap = ntiles;
     }
     float key[12 + 8];
     memcpy(key, P.fwd, 12 * sizeof(float));  // fwd, right, up, pos: contiguous in RtParams
     const int ints[8] = {P.width, P.height, P.tile_col0, P.tile_cols, P.tile_row0, P.tile_rows, P.sphere_count, fused ? 1 : 0};
     memcpy(key + 12, ints, sizeof ints);
-    if (!c->lists_valid || memcmp(key, c->lists_key, sizeof key) != 0) {
-        c->lists_valid = false;
-        const hipError_t e = rt_launch_tile_lists(P, fused, c->d_tile_lists, c->stream);
-        if (e != hipSuccess) return fail(RT_E_HIP, "tile list kernel launch: %s", hipGetErrorString(e));
-        memcpy(c->lists_key, key, sizeof key);
-        c->lists_valid = true;
+    if (!c->hits_valid || memcmp(key, c->hits_key, sizeof key) != 0) {
+        c->hits_valid = false;
+        const hipError_t e = rt_launch_camera_hits(P, fused, c->d_cam_hits, c->stream);
+        if (e != hipSuccess) return fail(RT_E_HIP, "camera hit kernel launch: %s", hipGetErrorString(e));
+        memcpy(c->hits_key, key, sizeof key);
+        c->hits_valid = true;
     }
-    P.tile_lists = c->d_tile_lists;
-    // a list entry costs a literal test of every camera lane, ~60 instructions; a pass of the sieve
-    // about 4 per sphere: lists pay up to about a fifteenth of the sphere count
-    P.tile_list_max = std::min(RT_TILE_LIST_WORDS - 1, std::max(4, P.n_pad / 16));
+    P.cam_hits = c->d_cam_hits;
     return RT_OK;
 }
 
@@ -950,16 +946,24 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     // Culled and bvh kernels out of LDS: 1000 spheres 13.3 -> 9.1 ms (bvh) and 19.3 -> 13.8 ms (culled), 4096
     // spheres 5.8 -> 4.7 ms and 20.9 -> 16.3 ms.  The bvh kernel out of global memory is left as it is
     // (16 384 spheres 4.35 -> 4.75 ms: its dispatch is short and its tail is not what bounds it).
-    static const int lpt_min_spheres = env_int("RT_DEBUG_LPT_STREAM_SPHERES", 1000);  // development knob; < 0: never
+    static const int lpt_min_spheres = env_int("RT_DEBUG_LPT_STREAM_SPHERES", 0);  // development knob; < 0: never
     if (!record && mode != 6 && lpt_min_spheres >= 0 && P.sphere_count >= lpt_min_spheres &&
         (long long)P.total_pixels * P.n_frames >= (1 << 22))
         use_tile_order(c, P, true, true);
-    if (!record && mode != 2) {
-        const int rc = use_tile_lists(c, P, fused);
+    P.cam_reuse = !record && c->camera_shortcuts;
+    if (!record) {
+        const int rc = use_camera_hits(c, P, fused);
         if (rc != RT_OK) return rc;
-        // the per-lane traversal is cheap where a list is long (dense scenes: 4096 spheres 6.4 -> 6.0 Grays/s with
-        // lists of up to 31), so it takes short lists only (484 spheres 23.0 -> 26.3, 16 384 spheres 6.0 -> 6.4)
-        if (mode == 4 || mode == 6) P.tile_list_max = std::min(P.tile_list_max, 6);
+    }
+    // The shading reads the winning sphere's record (centre, radius, albedo): out of LDS where the workgroups of
+    // a CU leave room for a copy, else out of global memory (a gather that a wave of this kernel, three to a
+    // SIMD, has little else to cover with).
+    P.n_table = 0;
+    if (!record && P.n_pad > 0) {
+        const size_t per_cu = ((size_t)blocks + (size_t)c->cu_count - 1) / (size_t)c->cu_count;
+        const size_t with_table = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0,
+                                                      mode != 2 && mode != 4 && mode != 6 && P.sg_wide, P.n_pad);
+        if (with_table * per_cu <= kLdsPerCu) P.n_table = P.n_pad;
     }
     hipError_t e = hipSuccess;
     if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
@@ -1048,7 +1052,7 @@ int rt_destroy(rt_context* c)
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->d_split) (void)hipFree(c->d_split);
-    if (c->d_tile_lists) (void)hipFree(c->d_tile_lists);
+    if (c->d_cam_hits) (void)hipFree(c->d_cam_hits);
     if (c->d_perm) (void)hipFree(c->d_perm);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_rays) (void)hipFree(c->d_rays);
@@ -1085,7 +1089,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     if (cap > c->sphere_cap) {
         c->n_spheres = 0;  // until the new buffers are filled there is nothing to trace
         c->cull_count = -1;
-        c->lists_valid = false;
+        c->hits_valid = false;
         c->have_materials = false;
         if (c->d_spheres) HIP_TRY(hipFree(c->d_spheres));
         if (c->d_geom) HIP_TRY(hipFree(c->d_geom));
@@ -1141,7 +1145,7 @@ int rt_upload_spheres(rt_context* c, const void* aos, int count)
     c->n_spheres = count;
     c->have_materials = false;  // materials belong to a sphere list: upload them again
     c->cull_count = -1;         // so does the sorted copy of the culled kernel
-    c->lists_valid = false;     // and the per-tile lists of the spheres that camera rays can meet
+    c->hits_valid = false;      // and the hits of the camera rays
     host.resize(count);
     c->h_spheres.swap(host);
     return RT_OK;
@@ -1152,6 +1156,7 @@ int rt_upload_materials(rt_context* c, const float* kind_param, int count)
     if (!c) return fail(RT_E_INVALID, "ctx is null");
     RT_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hits_valid = false;  // a dielectric sphere is also hit from inside: the camera rays' hits may change
     if (count == 0 || !kind_param) {  // back to the reference's single surface response
         c->have_materials = false;
         return RT_OK;
@@ -1211,6 +1216,19 @@ int rt_set_kernel(rt_context* c, int kernel)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
+}
+
+int rt_set_option(rt_context* c, int option, int value)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    switch (option) {
+        case RT_OPTION_CAMERA_SHORTCUTS:
+            if (value != 0 && value != 1) return fail(RT_E_INVALID, "RT_OPTION_CAMERA_SHORTCUTS takes 0 or 1, got %d", value);
+            c->camera_shortcuts = value != 0;
+            return RT_OK;
+        default:
+            return fail(RT_E_INVALID, "unknown option %d", option);
+    }
 }
 
 int rt_set_tile_rows(rt_context* c, int row0, int row1)
@@ -1503,7 +1521,9 @@ int rt_get_counters(rt_context* c, rt_counters* out)
 #ifdef RT_COUNT_PASSES
     unsigned long long passes = 0;
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passes += slots[i * RT_RAY_SLOT_STRIDE + 1];
-    fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)rays / passes : 0.0);
+    unsigned long long passlanes = 0;
+    for (unsigned i = 0; i < RT_RAY_SLOTS; i++) passlanes += slots[i * RT_RAY_SLOT_STRIDE + 3];
+    fprintf(stderr, "passes %llu rays %llu lanes per pass %.2f\n", passes, rays, passes ? (double)passlanes / passes : 0.0);
     unsigned long long bvh[4];
     rt_bvh_step_counts(bvh);
     if (bvh[0])

@@ -8,14 +8,14 @@
 #include "rt_params.h"
 
 // ---- rt_kernels.hip
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma = false, int extra_float4 = 0, bool sg_wide = false);
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma = false, int extra_float4 = 0, bool sg_wide = false, int n_table = 0);
 hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode, int blocks, int threads,
                             hipStream_t st);
 hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays, unsigned long long* out,
                                 hipStream_t st);
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
 hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st);
-hipError_t rt_launch_tile_lists(const RtParams& P, bool fused, uint32_t* lists, hipStream_t st);
+hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, hipStream_t st);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, hipStream_t st);
 hipError_t rt_launch_rows(const RtParams& P, bool fused, int blocks, hipStream_t st);
 size_t rt_rows_lds_bytes(int threads);

@@ -464,6 +464,12 @@ __global__ void __launch_bounds__(64) rt_tile_kernel(const RtParams P)
 
 // -------------------------------------------------------------- stream kernel
 
+// Rays in flight in a wave of rt_stream_kernel at or below which it traces them one at a time with the
+// spheres dealt to its lanes (brute-force modes with the geometry in LDS).
+#ifndef RT_STREAM_TEAM_MAX
+#define RT_STREAM_TEAM_MAX 4
+#endif
+
 // Per-ray constants of the sieve.
 struct SieveRay {
     v2f nnx, nny, nnz;     // -d / |d|
@@ -966,13 +972,16 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&s_bin[cls(cost[i])], 1u)] = i;
 }
 
-// The spheres that the camera rays of each 8x8 tile can meet, for rt_stream_kernel: the cone test of
-// rt_lite_kernel (tile_cone_keeps) over the whole sphere list, 64 spheres at a time, a lane each.
-// lists: RT_TILE_LIST_WORDS words per tile of the dispatched region -- the count, then the indices
-// in ascending order; a count above RT_TILE_LIST_WORDS - 1 says "too many to list".
-// One wave per tile; blockDim.x = a multiple of 64.
+// Nearest hit of the camera ray of every pixel, for rt_stream_kernel.  The camera ray of a pixel is the
+// same ray in every frame (shader.comp:73-90: origin and direction depend on camera and pixel only), so
+// its Trace() gives the same sphere and the same distance in every frame and every dispatch until camera,
+// image, spheres or float profile change.  One wave per 8x8 tile, a lane per pixel: the cone test of
+// rt_lite_kernel (tile_cone_keeps) over the whole sphere list, 64 spheres at a time with a sphere per
+// lane, leaves the few spheres that any camera ray of the tile can meet; every lane then evaluates the
+// shader's own test (test_sphere) on those, in index order.  hits[tile * 64 + lane] = {sphere index or
+// -1, bits of t}.  blockDim.x = a multiple of 64.
 template <bool FUSED>
-__global__ void __launch_bounds__(256) rt_tile_lists_kernel(const RtParams P, uint32_t* lists)
+__global__ void __launch_bounds__(256) rt_camera_hits_kernel(const RtParams P, uint2* hits)
 {
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
@@ -995,21 +1004,27 @@ __global__ void __launch_bounds__(256) rt_tile_lists_kernel(const RtParams P, ui
     const float sin_t = __builtin_fmaf(__uint_as_float(wave_max_u32(__float_as_uint(__builtin_fabsf(sine)))), 1.0001f, 1e-6f);
     const float cos_t = __builtin_sqrtf(__builtin_fmaf(-sin_t, sin_t, 1.0f));
     const bool narrow = __ballot(!(along > 0.0f)) == 0ull && sin_t < 0.5f;  // wave-uniform
-    uint32_t* list = lists + (size_t)tile * RT_TILE_LIST_WORDS;
-    uint32_t total = 0;
-    for (int base = 0; base < P.sphere_count && total < (uint32_t)RT_TILE_LIST_WORDS; base += 64) {
+    Path p;
+    path_reset(p, P, dx, dy, dz);
+    const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
+    float best = RT_FLT_MAX;
+    int idx = -1;
+    for (int base = 0; base < P.sphere_count; base += 64) {
         const int i = base + (int)lane;
         bool keep = false;
         if (i < P.sphere_count) {
             const float4 sphere = *reinterpret_cast<const float4*>(P.spheres + i);
             keep = !narrow || tile_cone_keeps(P.pos[0], P.pos[1], P.pos[2], ux, uy, uz, sin_t, cos_t, sphere);
         }
-        const unsigned long long kept = __ballot(keep);
-        const uint32_t at = total + mbcnt64(kept);
-        if (keep && at < (uint32_t)RT_TILE_LIST_WORDS - 1u) list[1u + at] = (uint32_t)i;
-        total += (uint32_t)__popcll(kept);
+        for (unsigned long long todo = __ballot(keep); todo != 0ull; todo &= todo - 1ull) {
+            const int k = base + (int)__builtin_ctzll(todo);
+            bool far_root = false;
+            if (P.materials != nullptr) far_root = P.materials[k].x == 3.0f;
+            const float4 g = *reinterpret_cast<const float4*>(P.spheres + k);
+            test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, k, best, idx, far_root);
+        }
     }
-    if (lane == 0) list[0] = total;  // above RT_TILE_LIST_WORDS - 1: not all of them are in the list
+    hits[(size_t)tile * 64u + lane] = make_uint2((uint32_t)idx, __float_as_uint(best));
 }
 
 // ---------------------------------------------------------------- rows kernel
@@ -2120,7 +2135,7 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 #define RT_STREAM_SHADE(best_, idx_)                                                                                        \
     {                                                                                                                       \
         nrays++;                                                                                                            \
-        if (path_bounce<FUSED, RECORD>(p, P, idx_, best_, px, py, frame, rec, reinterpret_cast<const float4*>(P.spheres))) { \
+        if (path_bounce<FUSED, RECORD>(p, P, idx_, best_, px, py, P.frame0 + (uint32_t)(j * P.frame_stride), rec, table)) { \
             if constexpr (RECORD) record_light(P, px, py, j, p);                                                            \
             acc.x = p.lr + acc.x; /* vec4(light, 1.0) + accumulated */                                                      \
             acc.y = p.lg + acc.y;                                                                                           \
@@ -2141,6 +2156,34 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
             }                                                                                                               \
         }                                                                                                                   \
     }
+
+// The frames j .. n_frames - 1 of a pixel whose camera ray goes to the sky, all at once: every one of them is
+// one Trace() call and light = sky_color * (0.15, 0.15, 0.15) (shader.comp:94-102), added frame by frame in
+// the shader's order with the clears where they fall.  The pixel is stored and its lane is free.
+#define RT_STREAM_SKY_FRAMES                                                                                        \
+    {                                                                                                               \
+        path_reset(p, P, d0x, d0y, d0z);                                                                            \
+        (void)path_bounce<FUSED, false>(p, P, -1, RT_FLT_MAX, px, py, 0u, nullptr, nullptr);                        \
+        const unsigned left = (unsigned)(P.n_frames - j);                                                           \
+        for (; j < P.n_frames; j++) {                                                                               \
+            if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f); \
+            acc.x = p.lr + acc.x;                                                                                   \
+            acc.y = p.lg + acc.y;                                                                                   \
+            acc.z = p.lb + acc.z;                                                                                   \
+            acc.w = 1.0f + acc.w;                                                                                   \
+        }                                                                                                           \
+        nrays += left;                                                                                              \
+        nlist += left;                                                                                              \
+        store_pixel(P, px, py, acc);                                                                                \
+        if (P.tile_cost != nullptr)                                                                                 \
+            atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +                   \
+                          ((px >> 3) - (uint32_t)P.tile_col0),                                                      \
+                      nrays - pixel_rays0);                                                                         \
+        alive = false;                                                                                              \
+        start = false;                                                                                              \
+    }
+
+#define RT_CAM_UNKNOWN (-2)
 
 template <bool FUSED, bool RECORD, int MODE>
 __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
@@ -2169,9 +2212,13 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     const int n_frag = MFMA && !FAR_FRAGS ? P.n_lds * 4 : BVH ? P.n_bounds * 3 / 2 : 0;
     for (int i = threadIdx.x; i < n_frag; i += blockDim.x)
         frags[i] = BVH ? reinterpret_cast<const uint4*>(P.boxes)[i] : P.frags[i];
+    // the sphere records (centre, radius, albedo) that the shading reads, when there is room for them
+    float4* lds_table = reinterpret_cast<float4*>(frags + n_frag);
+    for (int i = threadIdx.x; i < 2 * P.n_table; i += blockDim.x) lds_table[i] = reinterpret_cast<const float4*>(P.spheres)[i];
+    const float4* table = P.n_table ? lds_table : reinterpret_cast<const float4*>(P.spheres);
     __syncthreads();  // the only barrier: waves run independently from here on
     const int sg_chunks = !SORTED && P.sg_wide ? RT_SG_CHUNKS_WIDE : RT_SG_CHUNKS;  // chunks between candidate walks
-    uint32_t* wmask = reinterpret_cast<uint32_t*>(frags + n_frag) + wave * (sg_chunks * 64);
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(lds_table + 2 * P.n_table) + wave * (sg_chunks * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
 
@@ -2214,14 +2261,20 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
 
     // lane state
     bool alive = false, start = false;
-    uint32_t px = 0, py = 0, frame = 0;
+    uint32_t px = 0, py = 0;
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned nrays = 0, nlist = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
 #ifdef RT_COUNT_PASSES
     unsigned npasses = 0;  // experiment: passes over the sphere list, added to the word after the ray counter
+    unsigned npasslanes = 0;  // and the lanes that held a ray in them (word 3)
 #endif
     float d0x = 0.f, d0y = 0.f, d0z = 0.f;  // camera-ray direction of the lane's pixel
+    // Nearest hit of the pixel's camera ray, which is the same in every frame of a dispatch (origin and
+    // direction depend on camera and pixel only, shader.comp:73-90): RT_CAM_UNKNOWN until it has been
+    // traced once, then the sphere index (-1: sky) and in cam_t the distance.  Only with P.cam_reuse.
+    int cam = RT_CAM_UNKNOWN;
+    float cam_t = RT_FLT_MAX;
     rt_record* rec = nullptr;
     Path p;
     p.ox = p.oy = p.oz = 0.f; p.dx = p.dy = p.dz = 0.f;
@@ -2269,11 +2322,15 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             }
             const uint32_t navail = span_end - span_cur;
             const uint32_t rank = mbcnt64(freem);
-            if (!alive && rank < navail) {
+            const bool took = !alive && rank < navail;
+            uint32_t took_tile = 0, took_l = 0;
+            if (took) {
                 const uint32_t pix = span_cur + rank;
                 const uint32_t l = pix & 63u;
                 // span -> tile: heaviest tiles of the previous dispatch first when their costs are known
                 const uint32_t tile = P.tile_order ? P.tile_order[pix >> 6] : pix >> 6;
+                took_tile = tile;
+                took_l = l;
                 // tile / tile_cols by multiplication: exact for tile < 2^24 (checked on the host)
                 const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
                 const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
@@ -2287,8 +2344,24 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                     if (!clear_at(P, 0, P.frame0)) acc = P.accum[(size_t)py * P.width + px];
                 alive = true;
                 start = true;
+                cam = RT_CAM_UNKNOWN;
             }
             span_cur += min((uint32_t)__popcll(freem), navail);
+
+            // ---- Trace() of the new pixels' camera rays: found once per camera and scene for every pixel
+            // (rt_camera_hits_kernel), the hit holds for every frame of the dispatch (cam, cam_t).  A pixel that
+            // sees the sky is finished here and now, all its frames, and its lane takes another pixel in the
+            // next round of this loop.
+            if constexpr (!RECORD) {
+                if (P.cam_hits != nullptr) {  // wave-uniform
+                    if (took) {
+                        const uint2 h = P.cam_hits[(size_t)took_tile * 64u + took_l];
+                        cam = (int)h.x;
+                        cam_t = __uint_as_float(h.y);
+                        if (cam < 0) RT_STREAM_SKY_FRAMES
+                    }
+                }
+            }
             freem = __ballot(!alive);
         }
         if (__ballot(alive) == 0ull) break;
@@ -2298,60 +2371,33 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         if (exhausted && rt_exhausted == 0) rt_exhausted = __builtin_amdgcn_s_memrealtime();
 #endif
 
-        // ---- a lane at the start of a path generates its camera ray
+        // ---- a lane at the start of a path whose camera ray's hit is known shades it at once and goes into
+        // the sieve below with its first bounce ray: every trip of the sieve is for 64 rays.  (More than one
+        // turn of this loop only at depth 1, where the camera ray is the whole path.)
+        if constexpr (!RECORD) {
+            while (__ballot(alive && start && cam >= 0) != 0ull) {
+                if (alive && start && cam >= 0) {
+                    if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    path_reset(p, P, d0x, d0y, d0z);
+                    start = false;
+                    nlist++;
+                    RT_STREAM_SHADE(cam_t, cam)
+                }
+            }
+        }
+        // ---- the others generate their camera ray
         if (start) {
-            frame = P.frame0 + (uint32_t)(j * P.frame_stride);
-            if (j > 0 && clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (RECORD) rec = record_slot(P, px, py, j);
             path_reset(p, P, d0x, d0y, d0z);
             start = false;
         }
-
-        // ---- Trace() of the camera rays: the rays of a tile leave one point within
-        // half a degree of one another, and the spheres that any of them can meet are listed per tile
-        // (rt_tile_lists_kernel).  The lanes that hold a camera ray -- mostly of one tile, a span is a
-        // tile -- run the literal test on that list, in index order, are shaded, and take their first
-        // bounce through the sieve below in this same trip: a trip advances such a lane by two rays.
-        // A lane whose camera ray ended its path (sky) sits the sieve out.
-        if constexpr (!RECORD && !CULL) {
-            if (P.tile_lists != nullptr) {  // wave-uniform
-                const bool camera = alive && p.bounce == 0;
-                unsigned long long todo = __ballot(camera);
-                if (todo != 0ull) {
-                    const uint32_t my_tile = ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +
-                                             ((px >> 3) - (uint32_t)P.tile_col0);
-                    const float a0 = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
-                    float best0 = RT_FLT_MAX;
-                    int idx0 = -1;
-                    bool listed = false;
-                    while (todo != 0ull) {
-                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, (int)__builtin_ctzll(todo));
-                        const bool mine = camera && my_tile == t;
-                        todo &= ~__ballot(mine);
-                        const uint32_t* list = P.tile_lists + (size_t)t * RT_TILE_LIST_WORDS;
-                        const uint32_t n = list[0];
-                        if (n > (uint32_t)P.tile_list_max) continue;  // too many for a list: these lanes go through the sieve
-                        if (mine) listed = true;
-                        for (uint32_t e = 0; e < n; e++) {
-                            const int i = (int)list[1u + e];
-                            bool far_root = false;
-                            if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
-                            const float4 g = *reinterpret_cast<const float4*>(P.spheres + i);
-                            if (mine) test_sphere<FUSED>(p, a0, g.x, g.y, g.z, g.w, i, best0, idx0, far_root);
-                        }
-                    }
-                    if (listed) {
-                        nlist++;
-                        RT_STREAM_SHADE(best0, idx0)
-                    }
-                }
-            }
-        }
-        const bool tracing = alive && !start;  // lanes with a ray for the sieve (all live ones, without the lists)
+        const bool tracing = alive;  // every live lane holds a ray now
         if (__ballot(tracing) == 0ull) continue;
 
 #ifdef RT_COUNT_PASSES
         npasses++;
+        npasslanes += (unsigned)__popcll(__ballot(tracing));
 #endif
         // ---- Trace(): sieve + candidate walk
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
@@ -2362,6 +2408,34 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             RT_MARK(t_walk)
         } else if constexpr (BVH_FAR) {
             trace_bvh_far<FUSED>(p, a, tracing, P, best, idx);
+            RT_MARK(t_walk)
+        } else if (!SORTED && P.n_lds != 0 && __popcll(__ballot(tracing)) <= RT_STREAM_TEAM_MAX) {  // wave-uniform
+            // ---- the few rays a wave is left with when the queues are dry (the mirror chains of up to max_depth
+            // bounces that a dispatch ends with), one after the other with the spheres dealt to the lanes: lane l
+            // evaluates shader.comp:44-60 for spheres l, l + 64, ... and the wave takes the minimum t, lowest index
+            // among equal ones -- what the shader's strict `<` in index order keeps.  A pass of sieve and walk
+            // costs a lone ray the same few thousand instructions as 64 of them.
+            for (unsigned long long todo = __ballot(tracing); todo != 0ull; todo &= todo - 1ull) {
+                const int from = (int)__builtin_ctzll(todo);
+                Path q;
+                q.ox = lane_value(p.ox, from); q.oy = lane_value(p.oy, from); q.oz = lane_value(p.oz, from);
+                q.dx = lane_value(p.dx, from); q.dy = lane_value(p.dy, from); q.dz = lane_value(p.dz, from);
+                const float qa = lane_value(a, from);
+                float t = RT_FLT_MAX;  // stays there unless one of this lane's spheres is hit at 0 < t < FLT_MAX
+                int hit = -1;
+                for (int i = lane; i < P.sphere_count; i += 64) {
+                    bool far_root = false;
+                    if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
+                    const float* f = gf + (i >> 1) * 8 + (i & 1);
+                    test_sphere<FUSED>(q, qa, f[0], f[2], f[4], radius[i], i, t, hit, far_root);
+                }
+                const uint32_t nearest = wave_min_u32(__float_as_uint(t));  // t > 0: ordered as its bits
+                const uint32_t lowest = wave_min_u32(__float_as_uint(t) == nearest ? (uint32_t)hit : 0xffffffffu);
+                if (lane == from && nearest != __float_as_uint(RT_FLT_MAX)) {
+                    best = __uint_as_float(nearest);
+                    idx = (int)lowest;
+                }
+            }
             RT_MARK(t_walk)
         } else {
             SieveRay sr;
@@ -2480,7 +2554,17 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             if (idx >= 0) idx = P.perm[idx];  // slot of the sorted list -> the shader's sphere index
 
         // ---- shade
-        if (tracing) RT_STREAM_SHADE(best, idx)
+        if (tracing) {
+            // a camera ray that went through the sieve (no list for its tile): its hit serves the pixel's other frames
+            const bool first = !RECORD && P.cam_reuse != 0 && p.bounce == 0;
+            if (first) {
+                cam = idx;
+                cam_t = best;
+            }
+            RT_STREAM_SHADE(best, idx)
+            if constexpr (!RECORD)
+                if (first && idx < 0 && alive) RT_STREAM_SKY_FRAMES
+        }
         RT_MARK(t_shade)
     }
 #ifdef RT_PHASE_TIMERS
@@ -2510,6 +2594,9 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     if (lane == 0)
         atomicAdd(P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 1,
                   (unsigned long long)npasses);
+    if (lane == 1)
+        atomicAdd(P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 3,
+                  (unsigned long long)npasslanes);
 #endif
 
     // The last workgroup to get here puts the work counters back to zero for the next launch:
@@ -2759,10 +2846,10 @@ static hipError_t launch_tile(const RtParams& P, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4, bool sg_wide)
+size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4, bool sg_wide, int n_table)
 {
     return (size_t)n_lds * (sizeof(float4) + sizeof(float) + (mfma ? 4 * sizeof(uint4) : 0)) +
-           (size_t)extra_float4 * sizeof(float4) +
+           (size_t)extra_float4 * sizeof(float4) + (size_t)n_table * 2 * sizeof(float4) +
            (size_t)(threads / 64) * (sg_wide ? RT_SG_CHUNKS_WIDE : RT_SG_CHUNKS) * 64 * sizeof(uint32_t);
 }
 
@@ -2776,7 +2863,7 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
     if (threads < 64 || threads % 64 != 0 || threads > (mode == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS))
         return hipErrorInvalidConfiguration;  // beyond the instantiation's launch bounds
     const bool sorted = mode == 2 || mode == 4 || mode == 6;
-    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0, !sorted && P.sg_wide);
+    size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0, !sorted && P.sg_wide, P.n_table);
     static const size_t pad = [] {
         const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
         return e ? (size_t)atol(e) : (size_t)0;
@@ -2849,13 +2936,13 @@ void rt_bvh_step_counts(unsigned long long out[4])
 
 size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4); }
 
-hipError_t rt_launch_tile_lists(const RtParams& P, bool fused, uint32_t* lists, hipStream_t st)
+hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, hipStream_t st)
 {
     const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows;
     if (fused)
-        hipLaunchKernelGGL((rt_tile_lists_kernel<true>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, lists);
+        hipLaunchKernelGGL((rt_camera_hits_kernel<true>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, hits);
     else
-        hipLaunchKernelGGL((rt_tile_lists_kernel<false>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, lists);
+        hipLaunchKernelGGL((rt_camera_hits_kernel<false>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, hits);
     return hipGetLastError();
 }
 

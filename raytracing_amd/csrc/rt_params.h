@@ -22,8 +22,6 @@ constexpr int RT_SG_CHUNKS = 16;
 // closer to one another: measured at 3840x2160, 4096 spheres 15.3 -> 14.8 ms, 1000 spheres 11.1 -> 10.8 ms
 // (16 384 spheres, where the walk reads global memory: 26.7 -> 29.0 ms, so not there).
 constexpr int RT_SG_CHUNKS_WIDE = 32;
-// Words per tile of RtParams::tile_lists: a count and up to 31 sphere indices.
-constexpr int RT_TILE_LIST_WORDS = 32;
 
 // Largest sphere count whose geometry stream is staged in LDS (16 B per sphere).
 #ifndef RT_MAX_LDS
@@ -97,6 +95,7 @@ struct RtParams {
     int sphere_count;  // loop bound of Trace(): ubo.sphereCount
     int n_pad;         // sphere_count rounded up to a multiple of RT_CHUNK
     int n_lds;         // spheres staged in LDS by the stream kernel: n_pad, or 0 when they do not fit
+    int n_table;       // stream kernel: sphere records (32 B each) staged in LDS for the shading: n_pad, or 0 (read from `spheres`)
     int width, height;
     int tile_col0;     // first column of 8x8 tiles rendered
     int tile_cols;     // number of tile columns rendered
@@ -137,10 +136,11 @@ struct RtParams {
     const uint32_t* tile_order;  // lite and stream kernels: k-th tile handed out -> tile of the dispatched region
                                  // (tiles in descending order of their cost in the previous dispatch), or null:
                                  // image order
-    const uint32_t* tile_lists;  // stream kernel, brute-force modes: per tile of the dispatched region RT_TILE_LIST_WORDS
-                                 // words -- the number of spheres that a camera ray of the tile can meet (or more than
-                                 // RT_TILE_LIST_WORDS - 1: too many to list) and their indices, ascending; null: none
-    int tile_list_max;           // lists longer than this are not used (the sieve is cheaper)
+    const uint2* cam_hits;       // stream kernel: per pixel of the dispatched region, [tile][pixel of the tile], the nearest
+                                 // hit of its camera ray {sphere index or -1, bits of t} (rt_camera_hits_kernel); null: none
+    int cam_reuse;               // stream kernel: != 0: the nearest hit of a pixel's camera ray (the same ray in every frame) is
+                                 // found once per dispatch and serves all the pixel's frames; 0 (then cam_hits == null):
+                                 // every Trace() call evaluates the whole sphere list, as the shader's loop does
     int split_tiles;             // lite kernel, with tile_order: the first split_tiles tiles of the order are traced by
                                  // split_ways waves each, a run of split_frames frames per wave (0: none)
     int split_ways;              // 2, 4 or 8

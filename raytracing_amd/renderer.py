@@ -28,6 +28,7 @@ KERNEL_BVH = 8
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1
 CLEAR_NEVER = 2
+OPTION_CAMERA_SHORTCUTS = 0
 
 RECORD_DTYPE = np.dtype([("hit", "<i4"), ("hash", "<u4", 3)])
 
@@ -99,6 +100,13 @@ class Renderer:
 
     def set_kernel(self, kernel: int) -> None:
         N.check(N.lib().rt_set_kernel(self._h, kernel))
+
+    def set_option(self, option: int, value: int) -> None:
+        N.check(N.lib().rt_set_option(self._h, option, value))
+
+    def set_camera_shortcuts(self, on: bool) -> None:
+        """False: every Trace() call evaluates the whole sphere list (RT_OPTION_CAMERA_SHORTCUTS)."""
+        self.set_option(OPTION_CAMERA_SHORTCUTS, 1 if on else 0)
 
     def set_tile_rows(self, row0: int, row1: int) -> None:
         N.check(N.lib().rt_set_tile_rows(self._h, row0, row1))
