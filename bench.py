@@ -272,10 +272,8 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
 
     def finish(total_steps):
         """The exchange step: sum the per-rank accumulation images on rank 0 and resolve."""
-        r.sync()
-        split.reduce(accum, dst=0)
+        split.reduce(accum, dst=0, renderer=r)  # ordered against the renderer's stream on the device, both ways
         if rank == 0:
-            torch.cuda.current_stream().synchronize()
             r.resolve(split.divisor(total_steps, fps))
 
     run_steps(args.warmup)
@@ -393,7 +391,8 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
     # Kernel time: two HIP events on the context's stream around the whole timed region (the launches run back
     # to back, two frames in flight, so region / launches bounds a launch from above).  Events around every
     # launch cost ~9 us of a ~45 us frame and, queued behind the previous launch, time its tail too.
-    loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers_next(accum.data_ptr(), colors[k].data_ptr()), image_of)
+    loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers_next(accum.data_ptr(), colors[k].data_ptr()), image_of,
+                           transfer_stream=(lambda: torch.cuda.current_stream().cuda_stream) if world > 1 and not staged else None)
     for i in range(args.warmup):
         loop.frame(ubos[i])
     loop.finish()

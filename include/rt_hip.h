@@ -207,6 +207,20 @@ int rt_bind_buffers_next(rt_context* ctx, void* accum_dev, void* color_dev);
    (src/engine/engine.cpp:48,132; config.hpp:12).  Returns at once when there is no such dispatch. */
 int rt_sync_dispatch(rt_context* ctx, int back);
 
+/* Ordering against another HIP stream of the same device without blocking the host -- the
+   semaphores between the reference's queue submissions (src/engine/engine.cpp:83-84,95-96,104-105)
+   and the per-slot fence of its frames in flight (engine.cpp:48,132), for callers that read or
+   write the images with work of their own (a copy, an RCCL send or reduce on the collective's stream).
+   rt_wait_stream: whatever is dispatched on the context AFTER this call starts only when everything
+     queued on hip_stream BEFORE this call has finished (the image a transfer still reads is not
+     overwritten by the next frame);
+   rt_stream_wait: whatever is queued on hip_stream AFTER this call starts only when everything
+     dispatched on the context BEFORE this call has finished (a transfer does not leave before its
+     frame is complete).
+   hip_stream is a hipStream_t; NULL is the default stream. */
+int rt_wait_stream(rt_context* ctx, void* hip_stream);
+int rt_stream_wait(rt_context* ctx, void* hip_stream);
+
 /* Re-resolve the colour image from the accumulation image with an explicit
    divisor: colour = unorm8(accum.rgb / divisor)  (shader.comp:129-132), used
    after a cross-GPU sum. */

@@ -58,6 +58,8 @@ SIGNATURES = {
     "rt_bind_buffers": (C.c_int, [_P, _P, _P]),
     "rt_bind_buffers_next": (C.c_int, [_P, _P, _P]),
     "rt_sync_dispatch": (C.c_int, [_P, C.c_int]),
+    "rt_wait_stream": (C.c_int, [_P, _P]),
+    "rt_stream_wait": (C.c_int, [_P, _P]),
     "rt_resolve": (C.c_int, [_P, C.c_float]),
     "rt_trace_crop": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rt_get_counters": (C.c_int, [_P, C.POINTER(Counters)]),

@@ -64,6 +64,8 @@ struct rt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done[2] = {nullptr, nullptr};  // recorded after every dispatch, alternating (rt_sync_dispatch)
     unsigned long long n_dispatch = 0;           // dispatches issued so far
+    hipEvent_t ev_order[4] = {nullptr, nullptr, nullptr, nullptr};  // rt_wait_stream / rt_stream_wait, used in turn
+    unsigned n_order = 0;
     int width = 0, height = 0;
 
     float4* accum_own = nullptr;
@@ -1023,6 +1025,8 @@ int rt_create(int device, int width, int height, rt_context** out)
         hipEventCreateWithFlags(&c->ev_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_done[1], hipEventDisableTiming) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipEventCreate failed"));
+    for (hipEvent_t& e2 : c->ev_order)
+        if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return bail(fail(RT_E_HIP, "hipEventCreate failed"));
     if (hipMalloc(&c->d_work, RT_WORK_BYTES) != hipSuccess || hipMalloc(&c->d_rays, RT_RAY_BYTES) != hipSuccess)
         return bail(fail(RT_E_HIP, "hipMalloc failed"));
     if (hipMemsetAsync(c->d_work, 0, RT_WORK_BYTES, c->stream) != hipSuccess ||
@@ -1064,6 +1068,8 @@ int rt_destroy(rt_context* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->ev_done)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_order)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1319,6 +1325,30 @@ int rt_bind_buffers_next(rt_context* c, void* accum_dev, void* color_dev)
     c->accum = accum_dev ? static_cast<float4*>(accum_dev) : c->accum_own;
     c->color = color_dev ? static_cast<uint32_t*>(color_dev) : c->color_own;
     return RT_OK;
+}
+
+// An event recorded on `from` that `to` waits for: what was queued on `from` before this call finishes
+// before anything queued on `to` after it starts; neither stream waits for the host.
+static int order_streams(rt_context* c, hipStream_t from, hipStream_t to)
+{
+    hipEvent_t ev = c->ev_order[c->n_order++ % 4u];
+    HIP_TRY(hipEventRecord(ev, from));
+    HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+    return RT_OK;
+}
+
+int rt_wait_stream(rt_context* c, void* hip_stream)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    RT_ON_DEVICE(c);
+    return order_streams(c, static_cast<hipStream_t>(hip_stream), c->stream);
+}
+
+int rt_stream_wait(rt_context* c, void* hip_stream)
+{
+    if (!c) return fail(RT_E_INVALID, "ctx is null");
+    RT_ON_DEVICE(c);
+    return order_streams(c, c->stream, static_cast<hipStream_t>(hip_stream));
 }
 
 int rt_dispatch_frames_timed(rt_context* c, int n_frames)

@@ -24,6 +24,15 @@ def _dist():
     return dist
 
 
+def _current_stream() -> int:
+    """The raw hipStream_t of torch's current stream: collectives on device tensors are ordered
+    against it (ProcessGroupNCCL makes its own stream wait for it, and Work.wait() makes it wait
+    for the collective)."""
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
 class SampleSplit:
     def __init__(self, rank: int, world: int):
         if not 0 <= rank < world:
@@ -52,10 +61,19 @@ class SampleSplit:
         else:
             renderer.dispatch(n)
 
-    def reduce(self, accum, dst: int = 0) -> None:
-        """Sum the per-rank accumulation images into rank `dst` (RCCL on GPUs, gloo on CPU)."""
+    def reduce(self, accum, dst: int = 0, renderer=None) -> None:
+        """Sum the per-rank accumulation images into rank `dst` (RCCL on GPUs, gloo on CPU).
+
+        With `renderer` (the context that renders into `accum`) the reduce is ordered against it on
+        the device, both ways and without blocking the host: it starts when the dispatches issued
+        so far are complete, and later dispatches -- which may clear or add to `accum` on any rank
+        -- start when it has read the image (over RCCL a collective returns once it is queued).
+        Without, the caller synchronises."""
         if self.world > 1:
             dist = _dist()
+            ordered = renderer is not None and accum.is_cuda
+            if ordered:
+                renderer.stream_wait(_current_stream())
             if accum.is_cuda and dist.get_backend() == "gloo":  # rehearsal on one GPU: stage through the host
                 host = accum.cpu()
                 dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
@@ -63,6 +81,8 @@ class SampleSplit:
                     accum.copy_(host)
             else:
                 dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+            if ordered:
+                renderer.wait_stream(_current_stream())
 
     def divisor(self, steps: int, frames_per_step: int) -> float:
         """The shader divides by frameCount + 1 (shader.comp:129); frameCount of the last frame
@@ -97,16 +117,17 @@ class TileSplit:
         if self.world == 1:
             return
         dist = _dist()
+        # Both sides use the batched primitive (over RCCL it runs on the world communicator; a plain
+        # send would lazily create a two-rank communicator that the batched receive does not use):
+        # all receives of a frame are one grouped launch on the display rank, one send on the others.
         if self.rank == dst:
-            # one batch: over RCCL all receives of a frame become one grouped launch instead of one per source
             ops = [dist.P2POp(dist.irecv, image[r0 * 8:r1 * 8], g)
                    for g, (r0, r1) in enumerate(self.bands) if g != dst and r1 > r0]
-            for q in dist.batch_isend_irecv(ops) if ops else []:
-                q.wait()
         else:
             r0, r1 = self.rows
-            if r1 > r0:
-                dist.send(image[r0 * 8:r1 * 8].contiguous(), dst=dst)
+            ops = [dist.P2POp(dist.isend, image[r0 * 8:r1 * 8], dst)] if r1 > r0 else []
+        for q in dist.batch_isend_irecv(ops) if ops else []:
+            q.wait()
 
 
 class InteractiveLoop:
@@ -121,24 +142,35 @@ class InteractiveLoop:
     `image_of(k)` is the H x W [x C] tensor of image k that is exchanged (a host copy when the
     backend cannot move device memory).  `on_frame(f, image)` is called on the display rank with
     every completed frame, in order.
+
+    `transfer_stream()` returns the raw HIP stream that the exchange of device images is queued
+    on (torch's current stream for RCCL), or is None when the exchange blocks the host (gloo, host
+    copies).  Over RCCL a send returns as soon as it is QUEUED, so the image it reads must not be
+    handed to the next dispatch by the host's say-so alone: after every exchange the renderer's
+    stream is made to wait for the transfer stream (Renderer.wait_stream), which is the fence of
+    the reference's frame slot (src/engine/engine.cpp:48,132) and costs the host nothing.
     """
 
     def __init__(self, tiles: TileSplit, renderer, bind_color, image_of, on_frame=None, dst: int = 0,
-                 dispatch=None):
+                 dispatch=None, transfer_stream=None):
         self.tiles, self.renderer, self.bind_color, self.image_of = tiles, renderer, bind_color, image_of
         self.on_frame, self.dst = on_frame, dst
         self.dispatch = dispatch or (lambda: renderer.dispatch(1))
+        self.transfer_stream = transfer_stream
         self.count = 0
 
     def _deliver(self, f: int) -> None:
         image = self.image_of(f % 2)
         self.tiles.gather(image, dst=self.dst)
+        if self.transfer_stream is not None:
+            # image f % 2 is written again by frame f + 2: not before this transfer has read it
+            self.renderer.wait_stream(self.transfer_stream())
         if self.on_frame is not None and self.tiles.rank == self.dst:
             self.on_frame(f, image)
 
     def frame(self, ubo) -> None:
         f = self.count
-        self.bind_color(f % 2)          # frame f-2, the last to write this image, was delivered a call ago
+        self.bind_color(f % 2)          # frame f-2, the last to write this image: its transfer is waited for on the device
         self.renderer.set_uniforms(ubo)
         self.dispatch()                 # asynchronous on a GPU, queued behind frame f-1
         if f > 0:

@@ -182,6 +182,15 @@ class Renderer:
         """Wait for the dispatch issued `back` dispatches ago (0: the last one, 1: the one before)."""
         N.check(N.lib().rt_sync_dispatch(self._h, back))
 
+    def wait_stream(self, hip_stream: int | None) -> None:
+        """Dispatches issued after this call start only when the work queued on `hip_stream` (a raw
+        hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) so far has finished."""
+        N.check(N.lib().rt_wait_stream(self._h, C.c_void_p(hip_stream)))
+
+    def stream_wait(self, hip_stream: int | None) -> None:
+        """Work queued on `hip_stream` after this call starts only when the dispatches issued so far have finished."""
+        N.check(N.lib().rt_stream_wait(self._h, C.c_void_p(hip_stream)))
+
     def trace_crop(self, n_frames: int, x0: int, y0: int, w: int, h: int, want_light: bool = True):
         """Records (n_frames, h, w, max_depth) and per-frame light (n_frames, h, w, 3)."""
         rec = np.empty((n_frames, h, w, self.max_depth), RECORD_DTYPE)
