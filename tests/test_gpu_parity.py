@@ -489,12 +489,12 @@ def test_shared_frames_under_the_other_clear_modes(rt, default_scene, clear):
             assert np.array_equal(r.read_color(), ccol), k
 
 
-def test_tile_lists_follow_camera_scene_and_size(rt, rtiow_scene):
-    """The stream kernel traces camera rays against per-tile lists of the spheres they can meet, computed
-    by a cone test and kept while camera, image and spheres stay.  One context through a still camera
-    (lists reused), a moved and a turned camera, a camera inside the scene, other spheres, another
-    image size and a band of tile rows: every image must be the oracle's, and the lists must have
-    been used (counter)."""
+def test_camera_hits_follow_camera_scene_and_size(rt, rtiow_scene):
+    """The stream kernel finds the hit of every pixel's camera ray once (a cone test per tile, then the
+    literal test of the few spheres left) and keeps it while camera, image and spheres stay.  One
+    context through a still camera (hits reused), a moved and a turned camera, a camera inside the
+    scene, other spheres, another image size and a band of tile rows: every image must be the
+    oracle's, and the hits must have been used (counter)."""
     scene = rtiow_scene
     w, h = 192, 112
     cams = []
@@ -522,7 +522,15 @@ def test_tile_lists_follow_camera_scene_and_size(rt, rtiow_scene):
             cnt = r.counters()
             cacc, ccol, crays = O.render(ubo, scene.spheres, w, h, n_frames=2, max_depth=6, threads=8)
             assert np.array_equal(_bits(r.read_accum()), _bits(cacc)) and np.array_equal(r.read_color(), ccol), k
-            assert cnt["rays"] == crays and 0 < cnt["list_rays"] <= cnt["paths"], (k, cnt)
+            assert cnt["rays"] == crays and cnt["list_rays"] == cnt["paths"], (k, cnt)
+        # the same camera with the shortcuts off: every Trace() call walks the sphere list; same bits
+        r.set_camera_shortcuts(False)
+        r.reset_counters()
+        r.dispatch(2)
+        cnt = r.counters()
+        assert np.array_equal(_bits(r.read_accum()), _bits(cacc)) and np.array_equal(r.read_color(), ccol)
+        assert cnt["rays"] == crays and cnt["list_rays"] == 0, cnt
+        r.set_camera_shortcuts(True)
         other = scene.spheres.copy()
         other["center"][3:200] += np.float32([0.0, 0.35, 0.0])    # most small spheres lifted off the ground
         r.upload_spheres(other)
@@ -545,7 +553,7 @@ def test_tile_lists_follow_camera_scene_and_size(rt, rtiow_scene):
 
 
 def test_span_order_of_large_scenes_does_not_show(rt):
-    """From 1000 spheres and 4 M paths per dispatch on, the stream kernel (brute force, culled and
+    """From 4 M paths per dispatch on, the stream kernel (brute force, culled and
     bvh alike) takes its spans heaviest tile first, by the ray counts the previous dispatch left
     behind, sorted anew every 8 dispatches.  Eleven dispatches (in image order, sorted, reused,
     sorted again) against the tile kernel (never ordered), whole image; and the oracle on a crop."""
@@ -713,34 +721,93 @@ def test_counters_follow_the_sphere_count_of_each_dispatch(rt, default_scene, ke
 
 # ---------------------------------------------------------------- full-size properties
 
-def test_full_size_4k_stream_equals_tile(rt, rtiow_scene):
-    """Headline size (3840x2160, ~500 spheres): too big for the oracle in seconds, so check the
-    two independently written kernels against each other over the whole image, the ray
-    counter, and the oracle on a strided sample of tiles."""
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_full_size_4k_stream_equals_tile(rt, rtiow_scene, pname, profile):
+    """Headline size (3840x2160, ~500 spheres), the launch the benchmark reports (matrix-core sieve out
+    of LDS, 768 threads, camera hits, spans in image order, then heaviest tiles first): too big
+    for the oracle in seconds, so check the two independently written kernels against each other
+    over the whole image after the first dispatch and after the third, the ray counter, and the
+    oracle on a strided sample of tiles."""
     w, h = 3840, 2160
     with rt.Renderer(w, h) as r:
-        r.set_profile(1)
+        r.set_profile(profile)
         r.upload_spheres(rtiow_scene.spheres)
         ubo = rtiow_scene.camera.copy()
         ubo["frameCount"][0] = 1
         r.set_uniforms(ubo)
         r.dispatch(2)
         a_stream, c_stream, n_stream = r.read_accum(), r.read_color(), r.counters()["rays"]
+        assert r.sieve_mode() == 3 and r.info()["threads"] == 768 and r.counters()["list_rays"] == w * h * 2
+        # two more dispatches go on accumulating: the second takes its spans heaviest tile first, the third reuses the order
+        for k in (1, 2):
+            u = ubo.copy()
+            u["frameCount"][0] = 1 + 2 * k
+            r.set_uniforms(u)
+            r.dispatch(2)
+        a_stream3, c_stream3, n_stream3 = r.read_accum(), r.read_color(), r.counters()["rays"]
         r.reset_counters()
         r.set_kernel(1)
+        r.set_uniforms(ubo)
         r.dispatch(2)
         a_tile, c_tile, n_tile = r.read_accum(), r.read_color(), r.counters()["rays"]
         assert np.array_equal(_bits(a_stream), _bits(a_tile))
         assert np.array_equal(c_stream, c_tile)
         assert n_stream == n_tile
         assert np.all(a_stream[:2160 // 8 * 8, :, 3] == 2.0)
+        for k in (1, 2):
+            u = ubo.copy()
+            u["frameCount"][0] = 1 + 2 * k
+            r.set_uniforms(u)
+            r.dispatch(2)
+        assert np.array_equal(_bits(a_stream3), _bits(r.read_accum())) and np.array_equal(c_stream3, r.read_color())
+        assert n_stream3 == r.counters()["rays"]
+        r.set_uniforms(ubo)
         for (x0, y0) in [(0, 0), (1912, 1080), (3832, 2152), (777, 1501)]:
             rec, light = r.trace_crop(2, x0, y0, 8, 8)
-            crec, clight = O.trace_crop(ubo, rtiow_scene.spheres, w, h, x0, y0, 8, 8, profile=1, n_frames=2)
+            crec, clight = O.trace_crop(ubo, rtiow_scene.spheres, w, h, x0, y0, 8, 8, profile=profile, n_frames=2)
             assert np.array_equal(rec["hit"], crec["hit"]) and np.array_equal(rec["hash"], crec["hash"])
             assert np.array_equal(_bits(light), _bits(clight))
             # the image holds exactly the sum of the recorded lights, in frame order
             assert np.array_equal(_bits(a_stream[y0:y0 + 8, x0:x0 + 8, :3]), _bits(clight[1] + (clight[0] + np.float32(0.0))))
+        # and the oracle itself, six frames deep, on two rows of tiles of the ordered dispatches' image
+        cacc, ccol, _ = O.render(ubo, rtiow_scene.spheres, w, h, profile=profile, n_frames=6, rows=(150, 152), threads=8)
+        assert np.array_equal(_bits(a_stream3[1200:1216]), _bits(cacc[1200:1216]))
+        assert np.array_equal(c_stream3[1200:1216], ccol[1200:1216])
+
+
+def test_stress_4096_spheres_as_the_benchmark_runs_it(rt):
+    """The 4096-sphere configuration through the path its benchmark takes: matrix-core sieve with the
+    operands streamed from L2, candidate walks every 1024 spheres, camera hits, and from the second
+    dispatch on spans of the heaviest tiles first (4 M paths a dispatch).  Three accumulating
+    dispatches (image order, sorted, order reused) against the tile kernel over the whole image and
+    the ray counts, and against the oracle on sampled rows of tiles."""
+    scene = rt.Scene.generate(rt.KIND_CUBE, 4096, 3)
+    w, h = 2048, 1024
+    ubo = scene.camera.copy()
+    out = {}
+    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
+        with rt.Renderer(w, h) as r:
+            r.set_kernel(kernel)
+            r.upload_spheres(scene.spheres)
+            for k in range(3):
+                u = ubo.copy()
+                u["frameCount"][0] = 1 + 2 * k
+                r.set_uniforms(u)
+                r.dispatch(2)
+                if kernel == rt.KERNEL_STREAM:
+                    assert r.sieve_mode() == 3 and r.info()["threads"] == 512
+            cnt = r.counters()
+            out[kernel] = (r.read_accum(), r.read_color(), cnt["rays"])
+            if kernel == rt.KERNEL_STREAM:
+                assert cnt["list_rays"] == cnt["paths"] == w * h * 6
+    a, b = out[rt.KERNEL_STREAM], out[rt.KERNEL_TILE]
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    u = ubo.copy()
+    u["frameCount"][0] = 1
+    for rows in ((3, 4), (64, 65), (127, 128)):
+        cacc, ccol, _ = O.render(u, scene.spheres, w, h, n_frames=6, rows=rows, threads=8)
+        y0, y1 = rows[0] * 8, rows[1] * 8
+        assert np.array_equal(_bits(a[0][y0:y1]), _bits(cacc[y0:y1])) and np.array_equal(a[1][y0:y1], ccol[y0:y1]), rows
 
 
 def test_default_scene_1080p_1024_frames(rt, default_scene):
