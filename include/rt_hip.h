@@ -29,6 +29,14 @@ extern "C" {
 typedef struct rt_context rt_context;
 typedef struct rt_scene rt_scene;
 
+/* Raised whenever a struct below grows, an array argument changes its length or an entry point
+   changes its meaning; rt_abi_version() returns the value the library was built with, so that a
+   binding compiled against another header can refuse to go on.  No reference counterpart.
+   3: rt_counters has four words, rt_debug_cull_audit writes seven, rt_set_option /
+      rt_wait_stream / rt_stream_wait exist, kernel value 7 is gone. */
+#define RT_ABI_VERSION 3
+int rt_abi_version(void);
+
 enum {
     RT_OK = 0,
     RT_E_INVALID = -1,  /* bad argument                              */
@@ -45,7 +53,12 @@ enum {
     RT_PROFILE_FUSED = 1   /* one fused multiply-add                 */
 };
 
-/* Which kernel runs a dispatch.  All give bit-identical images. */
+/* Which kernel runs a dispatch.  All give bit-identical images.  RT_KERNEL_STREAM is the product: it
+   picks by scene size.  RT_KERNEL_STREAM_CULLED and RT_KERNEL_BVH are the opt-in spatial hierarchy.  The
+   others force one of the kernels that RT_KERNEL_STREAM chooses among, or an older formulation of
+   it, and exist as cross-checks for the parity tests (TILE: the shader's own mapping, no sieve; STREAM_SGPR,
+   STREAM_LDS: the vector-ALU sieve, the latter being what rt_dispatch_static runs; STREAM_MFMA and
+   LITE: the default's choices forced outside their range). */
 enum {
     RT_KERNEL_STREAM = 0, /* the default: brute force, the kernel chosen by sphere count -- up to 64
                              traced spheres LITE, from 65 to 65536 persistent waves (a lane
@@ -71,9 +84,8 @@ enum {
                                   tiles first, and with 16 and more frames per dispatch the frames of the heavier
                                   tiles shared among 2 to 8 waves and joined in frame order (up to 1 GiB of device
                                   memory, allocated on first use).  RT_KERNEL_STREAM picks it for such scenes. */
-    RT_KERNEL_ROWS = 7,        /* at most 64 traced spheres (else STREAM): persistent waves whose lanes take work
-                                  path by path, (pixel, frame), and add each pixel's frames in order through
-                                  LDS. */
+    /* 7: a kernel of an earlier version (path-by-path work distribution for small scenes), removed when LITE
+          learnt to share a tile's frames among waves; the value stays unused */
     RT_KERNEL_BVH = 8          /* STREAM_CULLED's sorted sphere list walked as a hierarchy by every lane on its
                                   own: blocks of 64 slots and their groups of 8 behind axis-aligned boxes, the
                                   spheres of a group behind the sieve (readme.md:38, "BVH implementation");
@@ -257,8 +269,7 @@ int rt_set_launch(rt_context* ctx, int blocks, int threads_per_block);
 int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* threads);
 /* Where the last stream-kernel dispatch evaluated its sieve: 0 vector ALU with geometry from LDS,
    1 vector ALU with geometry through the scalar cache, 2 the culled variant, 3 the matrix cores,
-   4 the lite kernel (vector ALU, one wave per tile), 5 the rows kernel (vector ALU, work handed out
-   path by path), 6 the per-lane traversal; -1 when the last dispatch ran the tile kernel or nothing has been dispatched.
+   4 the lite kernel (vector ALU, one wave per tile), 6 the per-lane traversal; -1 when the last dispatch ran the tile kernel or nothing has been dispatched.
    No reference counterpart. */
 int rt_get_sieve_mode(rt_context* ctx, int* mode);
 
@@ -298,12 +309,17 @@ int rt_debug_cull_audit(rt_context* ctx, const float* rays, int n_rays, uint64_t
 int rt_debug_fail_next_launch(rt_context* ctx);
 
 /* One dispatch that allocates nothing.  No counterpart in the reference; it exists for callers
-   that cannot allocate device memory: code under HIP graph capture, tight serving loops,
-   harnesses that forbid hipMalloc.  Same kernels and same bits as
+   that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc.
+   (It is not made for HIP graph capture: it queries and sets the current device, sets a function
+   attribute before its launch and checks hipGetLastError, none of which a capturing stream
+   allows, and it takes the uniform block by value, so a replay would render the same frame.)
+   Same bits as
        rt_create + rt_upload_spheres + rt_set_uniforms + rt_set_max_depth + rt_set_profile +
        rt_bind_buffers + rt_dispatch_frames(n_frames)
-   with the defaults of a new context (RT_KERNEL_STREAM, whole image, frame stride 1,
-   RT_CLEAR_REFERENCE), but the device memory a context would own (work-queue counters, ray
+   with the defaults of a new context (whole image, frame stride 1, RT_CLEAR_REFERENCE), at the
+   speed of RT_KERNEL_STREAM_LDS above 64 spheres (the vector-ALU sieve, no camera-ray hits kept
+   between calls, spans in image order: about half the rate of a context's default kernel on a
+   484-sphere scene), because the device memory a context would own (work-queue counters, ray
    counters, repacked sieve geometry) is a static device array inside the library, about 100 KiB
    per GPU, held until the process ends.  Inputs and outputs are the caller's:
      spheres_aos32_dev  DEVICE pointer to n_spheres 32-byte spheres (includes/scene.hpp:31-36),

@@ -10,7 +10,7 @@ from .scene import (  # noqa: F401
 )
 from .renderer import (  # noqa: F401
     Renderer, RECORD_DTYPE, PROFILE_STRICT, PROFILE_FUSED, KERNEL_STREAM, KERNEL_TILE, KERNEL_STREAM_SGPR, KERNEL_STREAM_LDS,
-    KERNEL_STREAM_CULLED, KERNEL_STREAM_MFMA, KERNEL_LITE, KERNEL_ROWS, KERNEL_BVH,
+    KERNEL_STREAM_CULLED, KERNEL_STREAM_MFMA, KERNEL_LITE, KERNEL_BVH,
     CLEAR_REFERENCE, CLEAR_FIRST, CLEAR_NEVER, OPTION_CAMERA_SHORTCUTS,
 )
 from ._native import RtError  # noqa: F401

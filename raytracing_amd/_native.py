@@ -36,6 +36,7 @@ _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _F = C.POINTER(C.c_float)
 SIGNATURES = {
+    "rt_abi_version": (C.c_int, []),
     "rt_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _PP]),
     "rt_destroy": (C.c_int, [_P]),
     "rt_resize": (C.c_int, [_P, C.c_int, C.c_int]),
@@ -95,6 +96,7 @@ SIGNATURES = {
 }
 
 STATIC_MAX_SPHERES = 4096  # RT_STATIC_MAX_SPHERES of include/rt_hip.h
+ABI_VERSION = 3            # RT_ABI_VERSION of include/rt_hip.h
 
 _lib = None
 
@@ -113,6 +115,9 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        if handle.rt_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} speaks ABI version {handle.rt_abi_version()}, this binding {ABI_VERSION}: "
+                              "rebuild the library (make -C raytracing_amd/csrc)")
         _lib = handle
     return _lib
 

@@ -535,16 +535,10 @@ void stream_geometry(const rt_context* c, const RtParams& P, int* blocks, int* t
 bool wants_mfma(const rt_context* c, const RtParams& P)
 {
     // up to RT_MAX_MFMA_SPHERES with the operands in LDS, beyond with the operands in global memory
-    static const bool far_ok = [] {
-        const char* e = getenv("RT_DEBUG_MFMA_FAR");  // development knob: 0 = scenes above RT_MAX_MFMA_SPHERES stay on the vector ALU
-        return !e || atoi(e) != 0;
-    }();
+    static const bool far_ok = rt_dev_knob("RT_DEBUG_MFMA_FAR", 1) != 0;  // 0 = scenes above RT_MAX_MFMA_SPHERES stay on the vector ALU
     const int limit = far_ok || c->kernel == RT_KERNEL_STREAM_MFMA ? RT_MAX_MFMA_FAR_SPHERES : RT_MAX_MFMA_SPHERES;
     const bool can = c->have_frags && P.n_pad > 0 && P.n_pad <= limit;
-    static const int min_pad = [] {
-        const char* e = getenv("RT_DEBUG_MFMA_MIN_SPHERES");  // development knob: smallest padded count RT_KERNEL_STREAM hands to the matrix cores
-        return e ? atoi(e) : 64;
-    }();
+    static const int min_pad = rt_dev_knob("RT_DEBUG_MFMA_MIN_SPHERES", 64);  // smallest padded count RT_KERNEL_STREAM hands to the matrix cores
     return can && (c->kernel == RT_KERNEL_STREAM_MFMA || (c->kernel == RT_KERNEL_STREAM && P.n_pad >= min_pad));
 }
 
@@ -565,10 +559,7 @@ void rt_stream_geometry(int cu_count, int want_blocks, int want_threads, const R
     // sharing one copy of the operands (measured at 484 spheres, since camera rays go by tile lists and the
     // kernel no longer fills the issue port: 19.7-20.3 Grays/s against 18.7-19.3 for two workgroups of 256);
     // 512 or 256 threads when 768 do not fit in LDS
-    static const int t_env = [] {  // development knob
-        const char* e = getenv("RT_DEBUG_MFMA_THREADS");
-        return e ? atoi(e) : RT_MFMA_MAX_THREADS;
-    }();
+    static const int t_env = rt_dev_knob("RT_DEBUG_MFMA_THREADS", RT_MFMA_MAX_THREADS);
     int t_mfma = std::max(256, std::min(RT_MFMA_MAX_THREADS, t_env / 256 * 256));
     while (t_mfma > 256 && rt_stream_lds_bytes(P.n_lds, t_mfma, true, 0, P.sg_wide) > kLdsPerCu) t_mfma -= 256;
     if (t_mfma == 256 && rt_stream_lds_bytes(P.n_lds, 256, true, 0, P.sg_wide) * 2 > kLdsPerCu) t_mfma = 512;
@@ -656,64 +647,15 @@ void reset_work(rt_context* c)
     if (c->d_work) (void)hipMemsetAsync(c->d_work, 0, RT_WORK_BYTES, c->stream);
 }
 
-// Development knob: what RT_KERNEL_STREAM runs for scenes of at most 64 traced spheres: 2 = the
-// rows kernel, 1 = the lite kernel, 0 = the stream kernel itself, -1 (default) = by dispatch shape.
+// Development knob: what RT_KERNEL_STREAM runs for scenes of at most 64 traced spheres: 1 = the lite
+// kernel (the default), 0 = the stream kernel itself.
 int small_scene_kernel()
 {
-    static const int which = [] {
-        const char* e = getenv("RT_DEBUG_LITE");
-        return e ? atoi(e) : -1;
-    }();
+    static const int which = rt_dev_knob("RT_DEBUG_LITE", -1);
     return which;
 }
 
-int env_int(const char* name, int fallback)
-{
-    const char* e = getenv(name);
-    return e ? atoi(e) : fallback;
-}
-
-// Launch of rt_rows_kernel: 256-thread workgroups, as many per CU as its LDS holds, and units of
-// PX pixels x all frames with PX the power of two from 8 to 64 that brings a unit closest to a
-// thousand paths (a unit is what a wave cannot share: it bounds how far apart waves finish) and
-// whose rows, 64 / PX frames each, divide the dispatch.
-int launch_rows(rt_context* c, RtParams& P, bool fused)
-{
-    static const int per_cu_env = env_int("RT_DEBUG_ROWS_PER_CU", 0);  // development knobs
-    static const int lpx_env = env_int("RT_DEBUG_ROWS_LPX", 0);
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (int)std::max<size_t>(1, std::min<size_t>(5, kLdsPerCu / rt_rows_lds_bytes(256)));
-    const unsigned ntiles = P.total_pixels / 64u;
-    int blocks = c->blocks > 0 ? c->blocks : c->cu_count * per_cu;
-    blocks = (int)std::max(1u, std::min((unsigned)blocks, (ntiles + 3) / 4));
-    int lpx = 6;
-    while (lpx > 3 && (1 << lpx) * P.n_frames > 1024) lpx--;
-    if (lpx_env >= 3 && lpx_env <= 6) lpx = lpx_env;
-    while (P.n_frames % (64 >> lpx) != 0) lpx++;
-    P.rows_lpx = lpx;
-    // A unit's pixels are PX neighbours of one tile (rows_lgroup = rows_lpx).  Smaller groups
-    // scatter a unit over the image, which evens out the cost of units; measured, that loses more
-    // (neighbouring rays branch alike: walk and shading took twice as long) than it gains.
-    static const int lg_env = env_int("RT_DEBUG_ROWS_LGROUP", -1);
-    P.rows_lgroup = lg_env >= 0 && lg_env <= 6 ? lg_env : lpx;
-    if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
-        return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the rows kernel", P.tile_cols, P.tile_rows);
-    hipError_t e = hipSuccess;
-    if (c->fail_next_launch) {  // test hook: a launch that died half way, its span counters left as they were
-        c->fail_next_launch = false;
-        (void)hipMemsetAsync(c->d_work, 0xff, RT_WORK_BYTES, c->stream);
-        e = hipErrorLaunchFailure;
-    } else {
-        e = rt_launch_rows(P, fused, blocks, c->stream);
-    }
-    if (e != hipSuccess) {
-        reset_work(c);
-        return fail(RT_E_HIP, "rows kernel launch (%d x 256): %s", blocks, hipGetErrorString(e));
-    }
-    c->last_blocks = blocks;
-    c->last_threads = 256;
-    c->last_mode = 5;
-    return RT_OK;
-}
+int env_int(const char* name, int fallback) { return rt_dev_knob(name, fallback); }
 
 // Tiles in descending order of their cost in an earlier dispatch of the same region, for the
 // kernels that hand out whole tiles or spans of pixels (rt_tile_order_kernel): fills P.tile_order
@@ -857,19 +799,13 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     if (P.total_pixels == 0) return RT_OK;
     const bool fused = c->profile == RT_PROFILE_FUSED;
     const bool tile = c->kernel == RT_KERNEL_TILE;
-    // at most 64 traced spheres: the rows kernel (or the lite kernel: one wave per tile with the sieve)
+    // at most 64 traced spheres: the lite kernel (one wave per tile with the sieve)
     const bool small = !record && P.n_pad <= 2 * RT_CHUNK;
-    int which = c->kernel == RT_KERNEL_ROWS ? 2 : c->kernel == RT_KERNEL_LITE ? 1 : 0;
+    int which = c->kernel == RT_KERNEL_LITE ? 1 : 0;
     if (c->kernel == RT_KERNEL_STREAM) {
-        // The lite kernel.  (The rows kernel was the choice for many frames of a small image until
-        // the lite kernel began to share the frames of its heaviest tiles among several waves,
-        // use_frame_split: 1280x720 x 64 frames 0.79 ms against 1.45 ms, 640x360 x 64 frames 0.27
-        // against 0.54 ms.  Only the first dispatch of a region, which has no tile costs to go
-        // by yet, is slower than the rows kernel's on the smallest images.)
         const int env = small_scene_kernel();
         which = env >= 0 ? env : 1;
     }
-    if (small && which == 2) return launch_rows(c, P, fused);
     if (small && which == 1) {
         static const int threads_env = env_int("RT_DEBUG_LITE_THREADS", 0);  // development knob
         const int threads = threads_env >= 64 && threads_env <= 1024 ? threads_env / 64 * 64 : 256;
@@ -990,6 +926,8 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
 extern "C" {
 
 const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 int rt_create(int device, int width, int height, rt_context** out)
 {
@@ -1218,7 +1156,7 @@ int rt_set_profile(rt_context* c, int profile)
 int rt_set_kernel(rt_context* c, int kernel)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");
-    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_BVH)
+    if (kernel < RT_KERNEL_STREAM || kernel > RT_KERNEL_BVH || kernel == 7 /* a kernel since removed */)
         return fail(RT_E_INVALID, "unknown kernel %d", kernel);
     c->kernel = kernel;
     return RT_OK;
@@ -1374,6 +1312,10 @@ int rt_dispatch_frames_timed(rt_context* c, int n_frames)
         if (e != hipSuccess) rc = fail(RT_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
     }
     try {
+        // room for every pair in either list, so that rt_timed_total can move them without allocating
+        const size_t pairs = c->timed_pending.size() + c->timed_free.size() + 1;
+        c->timed_pending.reserve(pairs);
+        c->timed_free.reserve(pairs);
         (rc == RT_OK ? c->timed_pending : c->timed_free).push_back(ev);
     } catch (const std::bad_alloc&) {
         (void)hipEventDestroy(ev.first);
@@ -1390,16 +1332,21 @@ int rt_timed_total(rt_context* c, float* ms, int* dispatches)
     HIP_TRY(hipStreamSynchronize(c->stream));
     double total = 0.0;
     int n = 0;
+    hipError_t bad = hipSuccess;
     while (!c->timed_pending.empty()) {
         const auto ev = c->timed_pending.back();
         c->timed_pending.pop_back();
+        c->timed_free.push_back(ev);  // rt_dispatch_frames_timed reserved the room: no allocation here
         float t = 0.f;
         const hipError_t e = hipEventElapsedTime(&t, ev.first, ev.second);
-        c->timed_free.push_back(ev);  // capacity was reserved when it was pending: pending + free never grows here
-        if (e != hipSuccess) return fail(RT_E_HIP, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        if (e != hipSuccess) {  // the remaining pairs are still retired: nothing is left to be summed into a later total
+            bad = e;
+            continue;
+        }
         total += t;
         n++;
     }
+    if (bad != hipSuccess) return fail(RT_E_HIP, "hipEventElapsedTime: %s", hipGetErrorString(bad));
     *ms = (float)total;
     if (dispatches) *dispatches = n;
     return RT_OK;
@@ -1575,15 +1522,6 @@ int rt_get_counters(rt_context* c, rt_counters* out)
             const unsigned long long* q = slots + i * RT_RAY_SLOT_STRIDE + 8;
             w[0] += q[0]; w[1] += q[1]; w[2] = std::max(w[2], q[2]); w[3] = std::max(w[3], q[3]);
             w[4] = std::max(w[4], q[4]); w[5] += q[5];
-        }
-        if (c->last_mode == 5) {  // rows kernel: words 9, 12, 14, 15 hold its own phases
-            unsigned long long tc = 0, nc = 0, nr = 0, td = 0;
-            for (unsigned i = 0; i < RT_RAY_SLOTS; i++) {
-                const unsigned long long* q = slots + i * RT_RAY_SLOT_STRIDE;
-                tc += q[9]; nc += q[12]; nr += q[14]; td += q[15];
-            }
-            fprintf(stderr, "rows kernel per iteration: summing rows %.0f cycles (%.2f rows), refill steps %.2f, waiting for a run of units %.0f cycles\n",
-                    (double)tc / t[4], (double)nc / t[4], (double)nr / t[4], (double)td / t[4]);
         }
         const double nw = (double)std::max(1ull, w[5]);
         fprintf(stderr, "wave lifetime (us): mean %.1f, shortest %.1f, longest %.1f; after the queues ran dry: mean %.1f, longest %.1f\n",

@@ -17,8 +17,6 @@ hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_
 hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st);
 hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, hipStream_t st);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, hipStream_t st);
-hipError_t rt_launch_rows(const RtParams& P, bool fused, int blocks, hipStream_t st);
-size_t rt_rows_lds_bytes(int threads);
 #ifdef RT_COUNT_PASSES
 void rt_bvh_step_counts(unsigned long long out[4]);  // experiment build: traversal steps since the last call
 #endif
@@ -28,6 +26,20 @@ hipError_t rt_launch_sieve_audit(const RtParams& P, const float* rays, int n_ray
                                  hipStream_t st);
 hipError_t rt_launch_math_probe(int op, const float* a, const float* b, const float* c, float* out,
                                 int n, hipStream_t st);
+
+// Development knobs.  The tuning experiments behind the measured choices in this library read
+// RT_DEBUG_* environment variables, but only in a build with -DRT_DEV_KNOBS (tools/build_variant.sh
+// makes one); the shipped library ignores the environment, every knob is its default.
+#ifdef RT_DEV_KNOBS
+#include <cstdlib>
+inline int rt_dev_knob(const char* name, int fallback)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : fallback;
+}
+#else
+inline int rt_dev_knob(const char*, int fallback) { return fallback; }
+#endif
 
 // ---- rt_api.cpp
 // Sets the calling thread's error message (printf style) and returns `code`.

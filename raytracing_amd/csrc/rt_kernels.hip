@@ -8,7 +8,7 @@
 // Build with -ffp-contract=off: the only fused multiply-adds are the explicit ones of
 // the FUSED float profile, so every result is reproducible bit for bit on the CPU.
 //
-// Four kernels, same results:
+// Three kernels, same results:
 //   rt_tile_kernel   one wave per 8x8 tile, one lane per pixel, the sphere loop exactly as
 //                    the shader writes it.  The plain mapping, kept as the in-GPU cross-check.
 //   rt_stream_kernel persistent waves.  A lane whose pixel is finished takes the next pixel
@@ -29,8 +29,6 @@
 //                    per-lane walk down a hierarchy of bounding spheres (trace_bvh).
 //   rt_lite_kernel   at most 64 spheres: one wave per tile, no queues, sieve + walk from LDS,
 //                    lanes run their pixel's frames back to back.
-//   rt_rows_kernel   at most 64 spheres, many frames of a small image: persistent waves that hand
-//                    out work path by path and add each pixel's frames in order through LDS.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -681,8 +679,8 @@ __device__ __forceinline__ float lane_value(float v, int from)
 //     sphere and the wave takes the minimum t, lowest index among equal ones -- what the shader's
 //     strict `<` in index order keeps.
 // The workgroup first copies the sphere records and the sieve geometry into LDS and reads them
-// from there, the sieve in a loop over groups of sphere pairs that is not unrolled (see
-// rt_rows_kernel).  Through the scalar cache, as rt_stream_kernel reads the geometry, this kernel
+// from there, the sieve in a loop over groups of sphere pairs that is not unrolled (unrolled,
+// the compiler keeps the whole geometry in registers).  Through the scalar cache, as rt_stream_kernel reads the geometry, this kernel
 // has too few scalar registers: about half of the geometry was spilled into vector registers
 // lane by lane, and even a dispatch of one frame, where a wave makes one or two passes, came out
 // slower (79 against 70 us for 1080p).
@@ -1025,435 +1023,6 @@ __global__ void __launch_bounds__(256) rt_camera_hits_kernel(const RtParams P, u
         }
     }
     hits[(size_t)tile * 64u + lane] = make_uint2((uint32_t)idx, __float_as_uint(best));
-}
-
-// ---------------------------------------------------------------- rows kernel
-
-// reg with its lane `lane_sel` replaced by `value` (both wave-uniform)
-__device__ __forceinline__ uint32_t write_lane(uint32_t reg, uint32_t value, uint32_t lane_sel)
-{
-    return (threadIdx.x & 63u) == lane_sel ? value : reg;
-}
-
-// Small scenes (at most 64 traced spheres), persistent waves, work handed out PATH by path.
-//
-// rt_lite_kernel keeps a lane on one pixel for all frames of a dispatch, so the unit that can
-// move between waves is a whole tile x all its frames: 720p x 64 frames are only 14 400 such
-// units, between 64 and 512 passes each, for ~5000 wave slots, and the kernel ends with most of
-// the chip waiting for the heaviest tiles.  Here the unit a lane takes is one path, (pixel, frame):
-//   - A wave works through "rows" of 64 paths.  A row is PX pixels x 64/PX consecutive frames
-//     (PX = 64, 32, 16 or 8: the more frames a dispatch has, the fewer pixels, so that a "unit",
-//     PX pixels x all frames, stays around a thousand paths); the rows of a unit follow each
-//     other, then comes the wave's next unit.  A free lane takes the next path of the open row,
-//     whatever the other lanes are doing, so all lanes stay busy and a wave's work ends within
-//     a few passes of the last path it was given.
-//   - The accumulation of a pixel must add its frames in order (float addition is not
-//     associative; the shader adds frame after frame).  A lane that ends a path parks the path's
-//     light in an LDS slot of its row; lane q < PX of the wave OWNS pixel q of the unit being
-//     summed: once all 64 paths of the oldest open row have ended, the owners add their pixel's
-//     entries, frame by frame, to their accumulators (same operands, same order as the shader)
-//     and after the last frame store the texel.  RT_ROWS rows are open at most (the slots
-//     are a ring).
-//   - The first frame of a unit (and a frame that clears): the lane that traces the path loads
-//     the old texel when it starts and parks light + texel; the owner takes that sum as is.
-//   - Camera-ray directions depend on the pixel only: the lanes that trace a unit's first frame
-//     leave them in LDS for the other frames (all paths of a unit are handed out before the
-//     next unit's first, so one set of directions is enough).
-//   - Units are dealt round-robin into RT_ROWS_QUEUES global queues; a wave draws a run of
-//     consecutive units of its workgroup's queue with one atomic add, long runs while the queue
-//     is full and single units at its end (each request sized from the answer to the one
-//     before, and made one run ahead), then moves on to the other queues.
-//   - Sphere records for the walk and the shading, and the sieve's pair-packed geometry, are read
-//     from a copy in LDS.
-// blockDim.x = 256; dynamic LDS = rt_rows_lds_bytes(256).
-#ifndef RT_ROWS_WINDOW
-#define RT_ROWS_WINDOW 8
-#endif
-constexpr int RT_ROWS = RT_ROWS_WINDOW;
-static_assert((RT_ROWS & (RT_ROWS - 1)) == 0 && RT_ROWS <= 64, "the ring of row slots is indexed with a mask");
-#ifndef RT_ROWS_WAVES_PER_EU
-#define RT_ROWS_WAVES_PER_EU 4
-#endif
-#ifndef RT_ROWS_GROUP
-#define RT_ROWS_GROUP 2
-#endif
-#ifndef RT_ROWS_MAX_RUN
-#define RT_ROWS_MAX_RUN 16
-#endif
-constexpr unsigned RT_ROWS_QUEUES = 32;
-static_assert((2 * RT_ROWS_QUEUES + 1) * RT_QUEUE_STRIDE * 4 <= RT_WORK_BYTES, "work block too small");
-struct RowsWave {
-    float4 slot[RT_ROWS][64];    // light of a finished path (or light + old texel, see above)
-    float dir[3][64];            // camera-ray directions of the unit whose paths are being handed out
-    uint32_t row_unit[RT_ROWS];  // unit of each open row
-};
-
-// Owner lane's part of summing up one row: its pixel's FR entries (frames j0 .. j0 + FR - 1 of
-// the dispatch), read together and added in frame order.  An entry of the first frame, or of a
-// frame that clears, already holds light + old texel and replaces the accumulator.
-template <int FR>
-__device__ __forceinline__ void rows_sum(float4& acc, const float4* row, uint32_t lane, uint32_t lpx,
-                                         const RtParams& P, int j0)
-{
-    float4 v[FR];
-#pragma unroll
-    for (int k = 0; k < FR; k++) v[k] = row[((uint32_t)k << lpx) + lane];
-#pragma unroll
-    for (int k = 0; k < FR; k++) {
-        const int j = j0 + k;
-        if (j == 0 || clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) {  // wave-uniform
-            acc = v[k];
-        } else {
-            acc.x = v[k].x + acc.x;  // vec4(light, 1.0) + accumulated
-            acc.y = v[k].y + acc.y;
-            acc.z = v[k].z + acc.z;
-            acc.w = 1.0f + acc.w;
-        }
-    }
-}
-
-template <bool FUSED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_ROWS_WAVES_PER_EU, RT_ROWS_WAVES_PER_EU)))
-rt_rows_kernel(const RtParams P)
-{
-    extern __shared__ float4 smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // workgroup's copy of the traced spheres ({centre, radius}, {albedo, padding})
-    for (int i = threadIdx.x; i < 2 * P.sphere_count; i += blockDim.x)
-        smem[i] = reinterpret_cast<const float4*>(P.spheres)[i];
-    // and of their pair-packed sieve geometry
-    float4* lgeom = smem + 2 * 2 * RT_CHUNK;
-    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
-    RowsWave* W = reinterpret_cast<RowsWave*>(lgeom + 2 * RT_CHUNK + 16) + wave;  // 16: the piped sieve reads one group ahead
-    __syncthreads();  // the only barrier
-
-    // a unit = PX pixels of a tile x all frames; a row = PX pixels x FR frames = 64 paths
-    const uint32_t lpx = (uint32_t)P.rows_lpx;
-    const uint32_t PX = 1u << lpx, FR = 64u >> lpx;
-    const uint32_t rows_per_unit = (uint32_t)P.n_frames / FR;  // the host picks PX so that FR divides n_frames
-    const uint32_t nunits = P.total_pixels >> lpx;
-    // A unit is made of groups of G = 2^rows_lgroup neighbouring pixels: group k of unit u is
-    // group u + k * nunits of the image (pixels counted tile by tile).  G = PX, what the host
-    // passes, makes a unit PX neighbours of one tile.  A smaller G spreads a unit over the image
-    // and evens out the cost of units (paths on a sphere bounce up to max_depth times, paths into
-    // the sky once), but the lanes of a wave then branch apart: measured, walk and shading took
-    // twice as long, more than the better balance gained.
-    const uint32_t lg = (uint32_t)P.rows_lgroup;
-    auto pixel_of = [&](uint32_t unit, uint32_t pi, uint32_t& x, uint32_t& y) {
-        const uint32_t id = ((unit + (pi >> lg) * nunits) << lg) + (pi & ((1u << lg) - 1u));
-        const uint32_t tile = id >> 6, q = id & 63u;
-        const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
-        const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
-        x = ((uint32_t)P.tile_col0 + tx) * 8 + (q & 7u);
-        y = ((uint32_t)P.tile_row0 + ty) * 8 + (q >> 3);
-    };
-
-    // work queues: unit u belongs to queue u % RT_ROWS_QUEUES
-    uint32_t queue = blockIdx.x % RT_ROWS_QUEUES;
-    auto queue_len = [&](uint32_t q) -> uint32_t { return (nunits + RT_ROWS_QUEUES - 1 - q) / RT_ROWS_QUEUES; };
-    const uint32_t waves_per_queue = max(1u, gridDim.x * (blockDim.x >> 6) / RT_ROWS_QUEUES);
-    // long units are drawn one at a time and not ahead: a unit in hand is what a wave still has
-    // to do when the queues are dry
-    const bool small_units = (PX * (uint32_t)P.n_frames) < 512u;
-    auto run_length = [&](uint32_t left) -> uint32_t {
-        return small_units ? max(1u, min((uint32_t)RT_ROWS_MAX_RUN, left / (2u * waves_per_queue))) : 1u;
-    };
-    auto ask = [&](uint32_t q, uint32_t n) -> uint32_t {
-        uint32_t k = 0xffffffffu;
-        if (lane == 0) k = atomicAdd(P.work_counter + q * RT_QUEUE_STRIDE, n);
-        return k;
-    };
-    auto next_queue = [&](uint32_t q) -> uint32_t {
-        bool has = false;
-        if (lane < (int)RT_ROWS_QUEUES)
-            has = __hip_atomic_load(P.work_counter + lane * RT_QUEUE_STRIDE, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT) < queue_len((uint32_t)lane);
-        const unsigned long long m = __ballot(has);
-        if (m == 0ull) return RT_ROWS_QUEUES;
-        const unsigned long long after = m & ~((2ull << q) - 1ull);
-        return (uint32_t)__builtin_ctzll(after ? after : m);
-    };
-    uint32_t ahead_n = run_length(queue_len(queue) / 2u);
-    uint32_t ahead = ask(queue, ahead_n);  // the first answer is on its way while the wave sets up
-    bool have_ahead = true;
-    bool exhausted = false;
-    uint32_t run_cur = 0, run_end = 0;  // units of the current run (positions in the queue) not opened yet
-
-    // rows (wave-uniform)
-    uint32_t g_open = 0, g_done = 0;     // rows opened / rows summed into the accumulators
-    uint32_t i_cur = 64;                 // paths of the open row handed out
-    uint32_t r_open = rows_per_unit - 1; // row of its unit that is open
-    uint32_t u_open = 0;                 // its unit
-    uint32_t r_done = 0;                 // row of its unit that row g_done is
-
-    // geometry constants of the sieve
-    const bool two = P.n_pad > RT_CHUNK;  // one or two chunks of 32 spheres
-    const uint32_t valid0 = two ? 0xffffffffu : P.n_pad ? P.last_chunk_valid : 0u;
-    const uint32_t valid1 = two ? P.last_chunk_valid : 0u;
-    const int last_groups = (P.last_chunk_count + 2 * RT_ROWS_GROUP - 1) / (2 * RT_ROWS_GROUP);
-    const int groups0 = two ? RT_CHUNK / 2 / RT_ROWS_GROUP : last_groups;
-    const int groups1 = two ? last_groups : 0;
-
-    // lane state
-    bool alive = false;
-    uint32_t px = 0, py = 0, frame = 0;
-    uint32_t slot_at = 0;  // where the path's light goes: slot index, bit 31 = with the old texel added
-    // paths that have ended, per open row: lane s of this register counts for ring slot s (a
-    // register of which one lane at a time is read and written with a scalar lane index: the
-    // count is wave-uniform, and no LDS round trip stands between a row's last path and its sum)
-    uint32_t ended = 0;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f);   // old texel, for a path of a unit's first frame
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);  // accumulator of the pixel this lane owns
-    unsigned nrays = 0;
-    Path p;
-    p.ox = p.oy = p.oz = 0.f; p.dx = p.dy = p.dz = 0.f;
-    p.cr = p.cg = p.cb = 0.f; p.lr = p.lg = p.lb = 0.f; p.bounce = 0;
-
-#ifdef RT_PHASE_TIMERS
-    // experiment: shader-clock cycles this wave spends in each phase of its loop (see rt_stream_kernel)
-    unsigned long long t_refill = 0, t_sieve = 0, t_walk = 0, t_shade = 0, n_iter = 0;
-    unsigned long long t_commit = 0, n_commit = 0, n_refill = 0, t_draw = 0;
-    unsigned long long t_mark = __builtin_amdgcn_s_memtime();
-    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-#define RT_ROWS_MARK(acc)                                             \
-    {                                                                 \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
-        acc += t_ - t_mark;                                           \
-        t_mark = t_;                                                  \
-    }
-#else
-#define RT_ROWS_MARK(acc)
-#endif
-    for (;;) {
-        // ---- sum up the rows whose 64 paths have all ended, oldest first
-        while (g_done < g_open) {
-            const uint32_t s = g_done % RT_ROWS;
-            if (__builtin_amdgcn_readlane(ended, s) != 64u) break;
-            ended = write_lane(ended, 0u, s);
-            if ((uint32_t)lane < PX) {
-                const float4* row = &W->slot[s][0];
-                const int j0 = (int)(r_done * FR);
-                switch (lpx) {
-                    case 6: rows_sum<1>(acc, row, (uint32_t)lane, lpx, P, j0); break;
-                    case 5: rows_sum<2>(acc, row, (uint32_t)lane, lpx, P, j0); break;
-                    case 4: rows_sum<4>(acc, row, (uint32_t)lane, lpx, P, j0); break;
-                    default: rows_sum<8>(acc, row, (uint32_t)lane, lpx, P, j0); break;
-                }
-            }
-            if (r_done == rows_per_unit - 1u) {
-                if ((uint32_t)lane < PX) {
-                    uint32_t x, y;
-                    pixel_of(W->row_unit[s], (uint32_t)lane, x, y);
-                    store_pixel(P, x, y, acc);
-                }
-                r_done = 0;
-            } else {
-                r_done++;
-            }
-            g_done++;
-#ifdef RT_PHASE_TIMERS
-            n_commit++;
-#endif
-        }
-        RT_ROWS_MARK(t_commit)
-
-        // ---- free lanes take the next paths of the open row
-        unsigned long long freem = __ballot(!alive);
-        while (freem != 0ull) {
-#ifdef RT_PHASE_TIMERS
-            n_refill++;
-#endif
-            if (i_cur == 64) {  // open the next row
-                if (g_open - g_done >= (uint32_t)RT_ROWS) break;  // the ring of slots is full
-                if (r_open + 1u < rows_per_unit) {
-                    r_open++;
-                } else {
-                    if (exhausted) break;
-                    if (run_cur == run_end) {
-#ifdef RT_PHASE_TIMERS
-                        const unsigned long long td0 = __builtin_amdgcn_s_memtime();
-#endif
-                        if (!have_ahead) {
-                            ahead_n = 1u;
-                            ahead = ask(queue, 1u);
-                        }
-                        const uint32_t k = __builtin_amdgcn_readfirstlane(ahead);
-#ifdef RT_PHASE_TIMERS
-                        t_draw += __builtin_amdgcn_s_memtime() - td0;
-#endif
-                        const uint32_t len = queue_len(queue);
-                        have_ahead = false;
-                        if (k >= len) {
-                            queue = next_queue(queue);
-                            if (queue == RT_ROWS_QUEUES) {
-                                exhausted = true;
-                                break;
-                            }
-                            continue;
-                        }
-                        run_cur = k;
-                        run_end = min(k + ahead_n, len);
-                        if (small_units) {
-                            ahead_n = run_length(len - run_end);
-                            ahead = ask(queue, ahead_n);
-                            have_ahead = true;
-                        }
-                    }
-                    u_open = run_cur * RT_ROWS_QUEUES + queue;
-                    run_cur++;
-                    r_open = 0;
-                }
-                i_cur = 0;
-                if (lane == 0) W->row_unit[g_open % RT_ROWS] = u_open;
-                g_open++;
-            }
-            const uint32_t navail = 64u - i_cur;
-            const uint32_t rank = mbcnt64(freem);
-            if (!alive && rank < navail) {
-                const uint32_t i = i_cur + rank;           // path of the row
-                const uint32_t pi = i & (PX - 1u);         // pixel of the unit
-                const int j = (int)(r_open * FR + (i >> lpx));  // frame of the dispatch
-                const uint32_t g = g_open - 1u;
-                const uint32_t fr = P.frame0 + (uint32_t)(j * P.frame_stride);
-                const bool cleared = clear_at(P, j, fr);
-                const bool take = j == 0 || cleared;
-                pixel_of(u_open, pi, px, py);
-                frame = fr;
-                slot_at = ((g % RT_ROWS) * 64u + i) | (take ? 0x80000000u : 0u);
-                a0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j == 0 && !cleared) a0 = P.accum[(size_t)py * P.width + px];
-                float dx, dy, dz;
-                if (j == 0) {
-                    primary_direction<FUSED>(P, px, py, dx, dy, dz);
-                    if (P.n_frames > 1) {
-                        W->dir[0][pi] = dx;
-                        W->dir[1][pi] = dy;
-                        W->dir[2][pi] = dz;
-                    }
-                }
-                if (j != 0) {  // after the writes above: the first frame of the pixel may start in this very step
-                    dx = W->dir[0][pi];
-                    dy = W->dir[1][pi];
-                    dz = W->dir[2][pi];
-                }
-                path_reset(p, P, dx, dy, dz);
-                alive = true;
-            }
-            i_cur += min((uint32_t)__popcll(freem), navail);
-            freem = __ballot(!alive);
-        }
-        if (__ballot(alive) == 0ull) break;  // nothing handed out: the queues are dry and every row is summed
-        RT_ROWS_MARK(t_refill)
-#ifdef RT_PHASE_TIMERS
-        n_iter++;
-#endif
-
-        // ---- Trace(): sieve + candidate walk (rt_stream_kernel has the commentary)
-        const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
-        const SieveRay sr = sieve_ray(p, a, alive);
-        // The geometry is read from LDS anew in every pass (the offset is hidden from the
-        // optimiser, which would otherwise keep all of it in registers across passes).  Through
-        // the scalar cache, as rt_stream_kernel reads it, the scalar registers of this kernel do
-        // not suffice: half of the geometry was spilled into vector registers lane by lane.
-        unsigned goff = 0;
-        asm volatile("" : "+v"(goff));
-        const v4f* geom = reinterpret_cast<const v4f*>(lgeom) + goff;
-        // groups of RT_ROWS_GROUP sphere pairs, in a loop that is NOT unrolled: unrolled, the
-        // compiler issues all LDS reads of a chunk first and needs 256 registers to hold them
-#ifdef RT_ROWS_PIPE
-        uint32_t cand0 = ~sieve_chunk_piped<RT_ROWS_GROUP>(geom, sr, groups0) & valid0;
-        uint32_t cand1 = 0u;
-        if (two) cand1 = ~sieve_chunk_piped<RT_ROWS_GROUP>(geom + RT_CHUNK, sr, groups1) & valid1;
-#else
-        uint32_t cand0 = ~sieve_chunk_partial<RT_ROWS_GROUP>(geom, sr, groups0) & valid0;
-        uint32_t cand1 = 0u;
-        if (two) cand1 = ~sieve_chunk_partial<RT_ROWS_GROUP>(geom + RT_CHUNK, sr, groups1) & valid1;
-#endif
-        RT_ROWS_MARK(t_sieve)
-        float best = RT_FLT_MAX;
-        int idx = -1;
-        uint32_t cur = cand0;
-        int base = 0;
-        for (;;) {
-            if (cur == 0u && base == 0) {
-                cur = cand1;
-                base = RT_CHUNK;
-            }
-            if (__ballot(cur != 0u) == 0ull) break;
-            if (cur != 0u) {
-                const int b = __clz(cur);
-                cur &= ~(0x80000000u >> b);
-                const int i = base + b;
-                bool far_root = false;
-                if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;  // wave-uniform branch
-                const float4 g = smem[2 * i];
-                test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
-            }
-        }
-        RT_ROWS_MARK(t_walk)
-
-        // ---- shade; a lane whose path has ended parks its light and is free
-        bool ended_now = false;
-        if (alive) {
-            nrays++;
-            if (path_bounce<FUSED, false>(p, P, idx, best, px, py, frame, nullptr, smem)) {
-                float4 v = make_float4(p.lr, p.lg, p.lb, 0.f);
-                if (slot_at >> 31) {
-                    v.x = p.lr + a0.x;  // vec4(light, 1.0) + accumulated
-                    v.y = p.lg + a0.y;
-                    v.z = p.lb + a0.z;
-                    v.w = 1.0f + a0.w;
-                }
-                (&W->slot[0][0])[slot_at & 0x7fffffffu] = v;
-                alive = false;
-                ended_now = true;
-            }
-        }
-        // count the ended paths row by row (the lanes of a pass end paths of one to three rows)
-        for (unsigned long long fin = __ballot(ended_now); fin != 0ull;) {
-            const uint32_t r = (__builtin_amdgcn_readlane(slot_at, (uint32_t)__builtin_ctzll(fin)) >> 6) & (RT_ROWS - 1u);
-            const unsigned long long same = __ballot(ended_now && ((slot_at >> 6) & (RT_ROWS - 1u)) == r);
-            ended = write_lane(ended, __builtin_amdgcn_readlane(ended, r) + (uint32_t)__popcll(same), r);
-            fin &= ~same;
-        }
-        RT_ROWS_MARK(t_shade)
-    }
-#ifdef RT_PHASE_TIMERS
-    if (lane == 0) {
-        unsigned long long* slot =
-            P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE;
-        atomicAdd(slot + 3, t_refill);
-        atomicAdd(slot + 4, t_sieve);
-        atomicAdd(slot + 5, t_walk);
-        atomicAdd(slot + 6, t_shade);
-        atomicAdd(slot + 7, n_iter);
-        const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
-        atomicAdd(slot + 8, rt_end - rt_start);
-        atomicMax(slot + 10, rt_end - rt_start);
-        atomicMax(slot + 11, ~(rt_end - rt_start));
-        atomicAdd(slot + 13, 1ull);
-        atomicAdd(slot + 9, t_commit);   // the rows kernel uses these words for its own phases
-        atomicAdd(slot + 12, n_commit);
-        atomicAdd(slot + 14, n_refill);
-        atomicAdd(slot + 15, t_draw);
-    }
-#endif
-    add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave);
-
-    // the last workgroup to get here puts the unit counters back to zero (as rt_stream_kernel does)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned q = blockIdx.x % RT_ROWS_QUEUES;
-        const unsigned in_queue = (gridDim.x - q + RT_ROWS_QUEUES - 1) / RT_ROWS_QUEUES;
-        unsigned* all_done = P.work_counter + RT_ROWS_QUEUES * RT_QUEUE_STRIDE;
-        unsigned* queue_done = all_done + (1 + q) * RT_QUEUE_STRIDE;
-        if (atomicAdd(queue_done, 1u) == in_queue - 1) {
-            const unsigned nqueues = min(gridDim.x, RT_ROWS_QUEUES);
-            if (atomicAdd(all_done, 1u) == nqueues - 1)
-                for (unsigned i = 0; i <= 2 * RT_ROWS_QUEUES; i++) atomicExch(P.work_counter + i * RT_QUEUE_STRIDE, 0u);
-        }
-    }
 }
 
 // ------------------------------------------------- sieve on the matrix cores
@@ -2864,10 +2433,7 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
         return hipErrorInvalidConfiguration;  // beyond the instantiation's launch bounds
     const bool sorted = mode == 2 || mode == 4 || mode == 6;
     size_t lds = rt_stream_lds_bytes(P.n_lds, threads, mode == 3, mode == 4 ? P.n_bounds * 3 / 2 : 0, !sorted && P.sg_wide, P.n_table);
-    static const size_t pad = [] {
-        const char* e = getenv("RT_DEBUG_LDS_PAD");  // development knob: extra LDS per workgroup, to cap workgroups per CU
-        return e ? (size_t)atol(e) : (size_t)0;
-    }();
+    static const size_t pad = (size_t)rt_dev_knob("RT_DEBUG_LDS_PAD", 0);  // extra LDS per workgroup, to cap workgroups per CU
     lds += pad;
     if (mode == 2) {
         if (record)
@@ -2975,25 +2541,6 @@ hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_
         e = hipGetLastError();
     }
     return e;
-}
-
-size_t rt_rows_lds_bytes(int threads)
-{
-    return (3 * 2 * RT_CHUNK + 16) * sizeof(float4) + (size_t)(threads / 64) * sizeof(RowsWave);
-}
-
-hipError_t rt_launch_rows(const RtParams& P, bool fused, int blocks, hipStream_t st)
-{
-    const size_t lds = rt_rows_lds_bytes(256);
-    const void* fn = fused ? reinterpret_cast<const void*>(&rt_rows_kernel<true>)
-                           : reinterpret_cast<const void*>(&rt_rows_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (fused)
-        hipLaunchKernelGGL((rt_rows_kernel<true>), dim3(blocks), dim3(256), lds, st, P);
-    else
-        hipLaunchKernelGGL((rt_rows_kernel<false>), dim3(blocks), dim3(256), lds, st, P);
-    return hipGetLastError();
 }
 
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st)

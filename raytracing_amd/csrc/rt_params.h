@@ -104,8 +104,6 @@ struct RtParams {
     unsigned last_chunk_valid; // bit (31-n) set when sphere n of the last chunk is < sphere_count
     int last_chunk_count;      // spheres in the last chunk (1..32; 0 for an empty scene)
     int prefetch;              // stream kernel: waves ask for their next span one span ahead
-    int rows_lpx;              // rows kernel: log2 of the pixels per unit (3..6)
-    int rows_lgroup;           // rows kernel: log2 of the neighbouring pixels that stay together in a unit (0..3)
     int tile_row0;     // first row of 8x8 tiles rendered
     int tile_rows;     // number of tile rows rendered
     unsigned total_pixels;  // tile_cols * tile_rows * 64

@@ -23,7 +23,6 @@ KERNEL_STREAM_LDS = 3
 KERNEL_STREAM_CULLED = 4
 KERNEL_STREAM_MFMA = 5
 KERNEL_LITE = 6
-KERNEL_ROWS = 7
 KERNEL_BVH = 8
 CLEAR_REFERENCE = 0
 CLEAR_FIRST = 1

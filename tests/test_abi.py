@@ -92,3 +92,19 @@ def test_kernels_of_the_static_entry_point_need_no_scratch_memory():
             assert r["vgpr_spill_count"] <= 24, (k, r)
         else:
             assert r["vgpr_spill_count"] == 0, (k, r)
+
+
+def test_binding_and_library_agree_on_the_abi_version():
+    from raytracing_amd import _native
+
+    m = re.search(r"#define\s+RT_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m and int(m.group(1)) == _native.ABI_VERSION == _native.lib().rt_abi_version()
+
+
+def test_shipped_library_reads_no_development_knobs():
+    """RT_DEBUG_* environment variables are read only by a build with -DRT_DEV_KNOBS; the library that
+    ships must not look at the environment when it picks a kernel."""
+    from raytracing_amd import _native
+
+    blob = open(_native.LIB_PATH, "rb").read()
+    assert b"RT_DEBUG_" not in blob

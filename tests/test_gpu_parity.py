@@ -17,7 +17,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 PROFILES = [("strict", 0), ("fused", 1)]
-KERNELS = [("stream", 0), ("tile", 1), ("stream_sgpr", 2), ("stream_lds", 3), ("stream_mfma", 5), ("lite", 6), ("rows", 7)]
+KERNELS = [("stream", 0), ("tile", 1), ("stream_sgpr", 2), ("stream_lds", 3), ("stream_mfma", 5), ("lite", 6)]
 
 
 def _bits(a):
@@ -359,7 +359,7 @@ def test_accumulation_continues_without_clear(rt, default_scene):
     assert np.array_equal(_bits(acc), _bits(cacc)) and np.array_equal(col, ccol)
 
 
-@pytest.mark.parametrize("scene_name,kernel", [("default", 0), ("default", 7), ("rtiow", 0), ("rtiow", 8)],
+@pytest.mark.parametrize("scene_name,kernel", [("default", 0), ("default", 6), ("rtiow", 0), ("rtiow", 8)],
                          ids=["lite", "rows", "matrix", "bvh"])
 def test_tile_rows_and_frame_stride_split(rt, default_scene, rtiow_scene, scene_name, kernel):
     """The two multi-GPU partitions, on one GPU: bands of tile rows, and frames by stride; for the
@@ -671,7 +671,7 @@ def test_errors_are_reported(rt, default_scene):
         rt.Renderer(0, 10)
 
 
-@pytest.mark.parametrize("kernel", [0, 2, 5, 6, 7])
+@pytest.mark.parametrize("kernel", [0, 2, 5, 6])
 def test_failed_launch_is_followed_by_a_correct_one(rt, default_scene, kernel):
     """A launch that fails leaves the work-queue counters of the kernels that have them as they were
     (here: as a kernel that died half way would); the dispatch must say so, and the next one must

@@ -28,7 +28,7 @@ with rt.Renderer(64, 64) as r:
             print(f"iteration {it}, {time.time() - t0:.0f} s", flush=True)
         si = int(rng.integers(len(scenes)))
         w, h = sizes[int(rng.integers(len(sizes)))]
-        frames = int(rng.choice([1, 2, 3, 33, 64]))  # 32 frames and more: the rows kernel on small scenes
+        frames = int(rng.choice([1, 2, 3, 33, 64]))  # 16 frames and more: the frames of heavy tiles shared among waves on small scenes
         kernel = int(rng.choice([0, 2, 3, 4, 1, 5, 6, 7, 8]))
         launch = [(0, 0), (1, 64), (37, 128), (512, 256), (2048, 64), (256, 1024)][int(rng.integers(6))]
         if (r.width, r.height) != (w, h):

@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD = 1024
 PEAK_TFLOPS = 157.3
 EXECUTED_FLOP_PER_TEST = 15.0  # the sieve as compiled: 7 v_pk_fma_f32 + 1 v_pk_add_f32 per sphere PAIR = 30 flop / 2
-KERNELS = ("rt_stream_kernel", "rt_tile_kernel", "rt_lite_kernel", "rt_rows_kernel")
+KERNELS = ("rt_stream_kernel", "rt_tile_kernel", "rt_lite_kernel")
 
 
 def per_launch(path, timed):
