@@ -25,11 +25,16 @@ interactive workload splits SCREEN TILES: every rank traces a band of tile rows 
 and rank 0 gathers the rgba8 bands, the exchange of a frame overlapping the tracing of the next
 (strong scaling).
 
-Output: one JSON line on rank 0.  `roofline` prices the path-trace kernel against the FP32
-vector peak (the path has no matrix contraction) and, beside it, against HBM; `cpu_baseline`
-is the CPU oracle (a port of the shader, not the reference binary) on the host cores, on a
-bounded sample of the same workload.
+Output: one JSON line on rank 0.  `roofline` prices the algorithmic work of the path-trace kernel
+(21 FP32 flop per ray-sphere test that is evaluated) against the FP32 peak and, beside it, the
+matrix pipe (where the sieve's dot products run above 64 spheres), the vector ALU's busy share
+and HBM; `cpu_baseline` is the CPU oracle (a port of the shader, not the reference binary) on the
+host cores, on a bounded sample of the same workload.  A default run on one GPU (no --workload)
+also carries, measured after the headline's timed region, a short pass of each of the other four
+workloads (`configs`) and of the headline workload with the camera-ray shortcuts switched off
+(`brute_force_only`: every Trace() call walks the whole sphere list).
 """
+import copy
 import argparse
 import json
 import os
@@ -47,7 +52,7 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak
 MFMA_FLOP_PER_TEST = 128       # executed on the matrix cores per test: 4 MFMAs of 32x32x16 per 32x32 tests
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
 BYTES_PER_PIXEL_DISPATCH = 36  # float4 read + float4 write + rgba8 write
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 WORKLOADS = {
     "rtiow4k": dict(scene="rtiow", size=(3840, 2160), depth=50, fps=8, steps=8, warmup=2,
@@ -68,7 +73,10 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None)
     p.add_argument("--warmup", type=int, default=None)
-    p.add_argument("--workload", choices=list(WORKLOADS), default="rtiow4k")
+    p.add_argument("--workload", choices=list(WORKLOADS), default=None,
+                   help="default: rtiow4k, followed on one GPU by short passes of the other workloads (`configs`)")
+    p.add_argument("--no-shortcuts", action="store_true",
+                   help="RT_OPTION_CAMERA_SHORTCUTS off: every Trace() call evaluates the whole sphere list")
     p.add_argument("--frames-per-step", type=int, default=None)
     p.add_argument("--profile", choices=["strict", "fused"], default="strict")
     p.add_argument("--kernel", choices=["stream", "valu", "tile", "culled", "bvh"], default="stream",
@@ -82,6 +90,8 @@ def parse_args():
                    help="rtiow4k with the material extension (lambertian/metal/dielectric per sphere) switched on; "
                         "the headline line is quoted without it (the reference has one surface response)")
     a = p.parse_args()
+    a.side_configs = a.workload is None
+    a.workload = a.workload or "rtiow4k"
     w = WORKLOADS[a.workload]
     a.steps = w["steps"] if a.steps is None else a.steps
     a.warmup = w["warmup"] if a.warmup is None else a.warmup
@@ -210,8 +220,9 @@ def roofline(args, tests, launches, kernel_ms, pixels_per_launch, pmc_key, sieve
         "frac": achieved / PEAK_FP32_TFLOPS,
         "flop_per_test": FLOP_PER_TEST,
         "tests_not_evaluated": {"share_of_rays_x_spheres": listed_share,
-                                "why": "camera rays are traced against the few spheres that a ray of their 8x8 tile can "
-                                       "meet (a cone test per tile); `achieved` counts the other rays' tests only"},
+                                "why": "a pixel's camera ray is the same ray in every frame: its hit is found once per camera "
+                                       "and scene (cone test per 8x8 tile, literal test of the few spheres left) and reused; "
+                                       "`achieved` counts the other rays' tests only"},
         "kernel_ms_per_launch": launch_ms,
         "launches": launches,
         "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBPS,
@@ -263,6 +274,7 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
     r.set_profile(profile)
     r.set_kernel(kernel)
     r.set_max_depth(args.max_depth)
+    r.set_camera_shortcuts(not args.no_shortcuts)
     r.set_scene(scene)
 
     def run_steps(n_steps):
@@ -305,6 +317,7 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
     total_rays = float(stats[1])
     total_listed = float(stats[2])
 
+    line = None
     if rank == 0:
         info = r.info()
         line = {
@@ -324,7 +337,8 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
                 "workload": f"{args.workload}: {scene_text}, {scene.sphere_count} spheres traced, {w}x{h}, "
                             f"{fps} frames (spp) per step per GPU, max depth {args.max_depth}, "
                             f"float profile {args.profile}, kernel {args.kernel}"
-                            + (", material extension on" if args.materials else ""),
+                            + (", material extension on" if args.materials else "")
+                            + (", camera-ray shortcuts off" if args.no_shortcuts else ""),
                 "parallelism": f"samples split by frame number over {world} GPU(s), one RCCL sum-reduce at the end",
                 "launch": f"{info['blocks']} x {info['threads']}",
             },
@@ -335,8 +349,8 @@ def throughput(args, rank, world, device, backend, torch, dist, rt):
         }
         if args.cpu_seconds > 0 and world == 1:  # the CPU leg runs at N=1 only
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
     r.close()
+    return line
 
 
 def interactive_ubos(rt, n):
@@ -420,6 +434,7 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         elapsed, kernel_ms = float(tmax[0]), float(tmax[3])
+    line = None
     if rank == 0:
         info = r.info()
         ms = elapsed / args.steps * 1e3
@@ -447,8 +462,39 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds,
                                                 interactive_frames=ubos[args.warmup:])
-        print(json.dumps(line), flush=True)
     r.close()
+    return line
+
+
+def compact(line):
+    """What `configs` keeps of a workload's line."""
+    roof = line["roofline"]
+    out = {"value": round(line["value"], 4 if line["unit"] == "ms" else 1), "unit": line["unit"],
+           "kernel_ms": round(roof["kernel_ms_per_launch"], 4),
+           "frac": None if roof["frac"] is None else round(roof["frac"], 3),
+           "hbm_frac": round(roof["hbm"]["frac"], 4), "rays_per_path": round(line["rays_per_path"], 3),
+           "workload": line["config"]["workload"]}
+    return out
+
+
+def side_configs(args, device, torch, dist, rt):
+    """Short passes of the other workloads on this one GPU, after the headline's timed region: every
+    configuration the baseline names gets a number from the same run of the same command."""
+    out = {}
+    for name, wl in WORKLOADS.items():
+        if name == args.workload:
+            continue
+        a = copy.copy(args)
+        a.workload, a.cpu_seconds, a.max_depth, a.frames_per_step = name, 0.0, wl["depth"], wl["fps"]
+        a.steps, a.warmup = (200, 40) if name == "interactive" else (4, 2)
+        fn = interactive if name == "interactive" else throughput
+        out[name] = compact(fn(a, 0, 1, device, "nccl", torch, dist, rt))
+    a = copy.copy(args)
+    a.cpu_seconds, a.no_shortcuts, a.steps, a.warmup = 0.0, True, 4, 2
+    brute = compact(throughput(a, 0, 1, device, "nccl", torch, dist, rt))
+    brute["what"] = ("the headline workload with RT_OPTION_CAMERA_SHORTCUTS off: every Trace() call of every frame "
+                     "evaluates the whole sphere list, as the shader's loop does; same bits")
+    return out, brute
 
 
 def main():
@@ -483,10 +529,12 @@ def main():
         else:
             dist.init_process_group(backend)
     try:
-        if args.workload == "interactive":
-            interactive(args, rank, world, device, backend, torch, dist, rt)
-        else:
-            throughput(args, rank, world, device, backend, torch, dist, rt)
+        fn = interactive if args.workload == "interactive" else throughput
+        line = fn(args, rank, world, device, backend, torch, dist, rt)
+        if line is not None and args.side_configs and world == 1:
+            line["configs"], line["brute_force_only"] = side_configs(args, device, torch, dist, rt)
+        if line is not None:
+            print(json.dumps(line), flush=True)
     finally:
         if world > 1:
             dist.destroy_process_group()

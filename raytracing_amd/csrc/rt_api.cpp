@@ -824,10 +824,12 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 1);  // development knob; < 0: never
             if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false, P.n_frames >= 16 ? 8 : 128);
             use_frame_split(c, P);
+            P.cam_reuse = c->camera_shortcuts;  // the bundled camera pass of every frame
             e = rt_launch_lite(P, fused, threads, c->stream);
         }
         if (e != hipSuccess) return fail(RT_E_HIP, "lite kernel launch (%d threads): %s", threads, hipGetErrorString(e));
-        c->lite_paths += (unsigned long long)P.total_pixels * (unsigned)P.n_frames;  // camera rays traced against tile lists
+        if (c->camera_shortcuts)  // every camera ray is traced against its tile's candidates
+            c->lite_paths += (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
         c->last_mode = 4;
         return RT_OK;
     }

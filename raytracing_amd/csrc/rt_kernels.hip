@@ -795,7 +795,8 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         const bool keep = !narrow || tile_cone_keeps(p.ox, p.oy, p.oz, ux, uy, uz, sin_t, cos_t, own);
         tile_spheres = __ballot(keep && own_valid);
     }
-    bool camera_pass = true;  // every live lane is on the camera ray of its pixel: the first pass of every frame
+    const bool bundle = P.cam_reuse != 0;  // off: camera rays go through the sieve like every other ray
+    bool camera_pass = bundle;  // every live lane is on the camera ray of its pixel: the first pass of every frame
 
     bool waiting = false;  // the lane's path of this frame has ended, the next frame's is set up
     for (;;) {
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
                 alive = true;
                 waiting = false;
             }
-            camera_pass = true;
+            camera_pass = bundle;
             continue;
         }
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);

@@ -158,6 +158,7 @@ extern "C" int rt_dispatch_static(int device, void* hip_stream, const void* sphe
     P.max_depth = max_depth;
     P.frame_stride = 1;
     P.clear_mode = RT_CLEAR_REFERENCE;
+    P.cam_reuse = 1;  // a pixel's camera ray is traced in its first frame only (no buffer involved)
     P.spheres = static_cast<const RtSphereAos*>(spheres_aos32_dev);
     P.geom = reinterpret_cast<const float4*>(dev.base + kGeomAt);
     P.radius = reinterpret_cast<const float*>(dev.base + kRadiusAt);

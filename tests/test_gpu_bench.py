@@ -67,6 +67,26 @@ def test_bench_single_rank_line(workload, unit):
     assert workload in line["config"]["workload"] and "model" not in line["config"]
 
 
+def test_bench_default_line_carries_every_configuration():
+    """The command the driver runs (no --workload): the headline workload, and measured after its timed
+    region a short pass of each other configuration and of the headline with the camera-ray shortcuts off."""
+    res = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = _one_json_line(res.stdout)
+    assert KEYS <= set(line) and "rtiow4k" in line["config"]["workload"] and line["steps"] == 2
+    _check_roofline(line)
+    assert set(line["configs"]) == {"default720p_d8", "default1080p", "stress4096", "interactive"}
+    for name, c in line["configs"].items():
+        assert {"value", "unit", "kernel_ms", "frac", "hbm_frac"} <= set(c) and c["value"] > 0 and name in c["workload"], name
+        assert c["unit"] == ("ms" if name == "interactive" else "Mrays/s")
+    assert line["configs"]["interactive"]["value"] < 1.0  # ms per 1080p frame
+    brute = line["brute_force_only"]
+    assert brute["unit"] == "Mrays/s" and 0 < brute["value"] < line["value"] and "shortcuts off" in brute["workload"]
+    # with every test evaluated the algorithmic rate is rays x spheres x 21 flop over the kernel time
+    assert brute["frac"] > line["roofline"]["frac"]
+
+
 @pytest.mark.parametrize("kernel", ["culled", "bvh"])
 def test_bench_culled_kernel_does_not_claim_brute_force_flops(kernel):
     res = subprocess.run([sys.executable, "bench.py", "--kernel", kernel, "--steps", "2", "--warmup", "1",
