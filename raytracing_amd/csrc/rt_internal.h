@@ -15,6 +15,7 @@ hipError_t rt_launch_cull_audit(const RtParams& P, const float* rays, int n_rays
                                 hipStream_t st);
 hipError_t rt_launch_tile(const RtParams& P, bool fused, bool record, hipStream_t st);
 hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_t st);
+size_t rt_lite_handover_bytes(unsigned waves, int ways, int split_frames);
 hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, hipStream_t st);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, hipStream_t st);
 #ifdef RT_COUNT_PASSES

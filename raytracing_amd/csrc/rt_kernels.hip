@@ -737,7 +737,13 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
             slot -= split_slots - (uint32_t)P.split_tiles;
         }
     }
-    if (slot >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
+    // (a wave beyond the last tile stays for the barrier of the runs' hand-over through LDS and does nothing else)
+    const bool valid = slot < (uint32_t)P.tile_cols * (uint32_t)P.tile_rows;  // wave-uniform
+    if (!valid) {
+        if (!MANY || P.split_lds == 0) return;
+        slot = 0;
+        run = -1;
+    }
     // heaviest tiles first, when the previous dispatch left their costs (rt_tile_order_kernel)
     const uint32_t tile = P.tile_order ? P.tile_order[slot] : slot;
     const uint32_t lane = threadIdx.x & 63u;
@@ -749,9 +755,16 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     const int j_begin = MANY && run > 0 ? run * P.split_frames : 0;
     const int j_end = !MANY ? 1 : run >= 0 ? min(P.n_frames, j_begin + P.split_frames) : P.n_frames;
     // runs after the first leave their lights here, a frame after the other, for rt_lite_join_kernel
-    float4* lights = MANY && run > 0 ? P.split_lights + ((size_t)slot * (ways - 1u) + (size_t)(run - 1)) *
-                                                            (size_t)P.split_frames * 64u + lane
-                                     : nullptr;
+    // ... in global memory, or, where the runs of a tile are waves of one workgroup and their lights fit, in LDS:
+    // per tile of the workgroup (ways - 1) * split_frames entries of three planes of 64 floats
+    const bool lds_handover = MANY && P.split_lds != 0;  // wave-uniform
+    float4* lights = MANY && run > 0 && !lds_handover
+                         ? P.split_lights + ((size_t)slot * (ways - 1u) + (size_t)(run - 1)) * (size_t)P.split_frames * 64u + lane
+                         : nullptr;
+    float* lds_lights = nullptr;  // this tile's entries, at this lane
+    if (lds_handover && run >= 0)
+        lds_lights = reinterpret_cast<float*>(lgeom + 2 * RT_CHUNK) +
+                     (size_t)((threadIdx.x >> 6) / ways) * (ways - 1u) * (size_t)P.split_frames * 192u + lane;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (run <= 0 && !clear_at(P, 0, P.frame0)) acc = P.accum[at];
     float d0x, d0y, d0z;
@@ -774,7 +787,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     unsigned nrays = 0;
     Path p;
     path_reset(p, P, d0x, d0y, d0z);
-    bool alive = j < j_end;
+    bool alive = valid && j < j_end;
 
     // the spheres that the camera rays of this tile can meet: the cone around the ray of pixel (3, 3)
     // that holds the 64 directions as they were computed (sine of the largest angle, a little more)
@@ -878,6 +891,11 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
             if (path_bounce<FUSED, false>(p, P, idx, best, px, py, frame, nullptr, smem)) {
                 if (MANY && lights != nullptr) {
                     lights[(size_t)(j - j_begin) * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);
+                } else if (MANY && lds_handover && run > 0) {
+                    float* at_l = lds_lights + (size_t)(j - P.split_frames) * 192u;  // run r, frame k of it: (r - 1) * split_frames + k
+                    at_l[0] = p.lr;
+                    at_l[64] = p.lg;
+                    at_l[128] = p.lb;
                 } else {
                     acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
                     acc.y = p.lg + acc.y;
@@ -897,8 +915,26 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
             }
         }
     }
-    if (run < 0) store_pixel(P, px, py, acc);
-    if (run == 0) P.accum[at] = acc;  // the sum so far; rt_lite_join_kernel adds the other runs' lights and resolves
+    if (lds_handover) {
+        // the runs of a tile meet here: the first one adds the others' lights in frame order, as one wave tracing
+        // all frames would have added them (float addition does not associate), and stores the pixel
+        __syncthreads();
+        if (run == 0) {
+            for (int jj = P.split_frames; jj < P.n_frames; jj++) {
+                if (clear_at(P, jj, P.frame0 + (uint32_t)(jj * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* at_l = lds_lights + (size_t)(jj - P.split_frames) * 192u;
+                acc.x = at_l[0] + acc.x;  // vec4(light, 1.0) + accumulated
+                acc.y = at_l[64] + acc.y;
+                acc.z = at_l[128] + acc.z;
+                acc.w = 1.0f + acc.w;
+            }
+        }
+        if (valid && run <= 0) store_pixel(P, px, py, acc);
+    } else {
+        if (run < 0) store_pixel(P, px, py, acc);
+        if (run == 0) P.accum[at] = acc;  // the sum so far; rt_lite_join_kernel adds the other runs' lights and resolves
+    }
+    if (!valid) return;
     // (every camera ray of this kernel is traced against its tile's list: the host counts them, a path each)
     const unsigned long long wave_rays = add_rays(P, nrays, tile);
     // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
@@ -2501,7 +2537,16 @@ void rt_bvh_step_counts(unsigned long long out[4])
 }
 #endif
 
-size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4); }
+#ifndef RT_LITE_LDS_EXTRA
+#define RT_LITE_LDS_EXTRA 0
+#endif
+size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4) + RT_LITE_LDS_EXTRA; }
+
+// LDS for the lights that the runs of the split tiles of a workgroup of `waves` waves hand to their first run.
+size_t rt_lite_handover_bytes(unsigned waves, int ways, int split_frames)
+{
+    return (size_t)(waves - waves / (unsigned)ways) * (size_t)split_frames * 192u * sizeof(float);
+}
 
 hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, hipStream_t st)
 {
@@ -2524,9 +2569,14 @@ hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_
     // one wave per tile, split_ways for each of the first P.split_tiles tiles of the order
     const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows +
                            (P.split_tiles > 0 ? (unsigned)P.split_tiles * (unsigned)(P.split_ways - 1) : 0u);
-    const unsigned per = (unsigned)threads / 64u;
+    unsigned per = (unsigned)threads / 64u;
+    size_t lds = rt_lite_lds_bytes();
+    if (P.split_lds) {  // the runs of a tile in one workgroup, their lights beside the geometry
+        per = std::max(per, (unsigned)P.split_ways);
+        threads = (int)per * 64;
+        lds += rt_lite_handover_bytes(per, P.split_ways, P.split_frames);
+    }
     const dim3 grid((tiles + per - 1) / per), block(threads);
-    const size_t lds = rt_lite_lds_bytes();
     const bool many = P.n_frames != 1 || P.split_tiles > 0;
     if (fused && many)
         hipLaunchKernelGGL((rt_lite_kernel<true, true>), grid, block, lds, st, P);
@@ -2537,7 +2587,7 @@ hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_
     else
         hipLaunchKernelGGL((rt_lite_kernel<false, false>), grid, block, lds, st, P);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && P.split_tiles > 0) {
+    if (e == hipSuccess && P.split_tiles > 0 && !P.split_lds) {
         hipLaunchKernelGGL(rt_lite_join_kernel, dim3((P.split_tiles + 3) / 4), dim3(256), 0, st, P);
         e = hipGetLastError();
     }

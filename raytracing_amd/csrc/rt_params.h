@@ -143,6 +143,9 @@ struct RtParams {
                                  // split_ways waves each, a run of split_frames frames per wave (0: none)
     int split_ways;              // 2, 4 or 8
     int split_frames;            // ceil(n_frames / split_ways)
+    int split_lds;               // != 0: the runs of a tile are waves of one workgroup and hand their lights to the first run
+                                 // through LDS, which joins them at the end of the kernel; 0: through split_lights and
+                                 // rt_lite_join_kernel
     float4* split_lights;        // the light of every path of the runs after a tile's first:
                                  // [tile of the order][run - 1][frame of the run][pixel of the tile]
     uint32_t* tile_cost;         // rays of each tile in this dispatch are left here (may be null): stored by the
