@@ -812,6 +812,9 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     bool camera_pass = bundle;  // every live lane is on the camera ray of its pixel: the first pass of every frame
 
     bool waiting = false;  // the lane's path of this frame has ended, the next frame's is set up
+    bool have_cam = false;  // wave-uniform: cam_idx, cam_t hold the hit of the lane's camera ray
+    int cam_idx = -1;
+    float cam_t = RT_FLT_MAX;
     for (;;) {
         const unsigned long long alive_mask = __ballot(alive);
         if (alive_mask == 0ull) {
@@ -828,14 +831,23 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
         float best = RT_FLT_MAX;
         int idx = -1;
         if (camera_pass) {  // wave-uniform
-            // ---- Trace() of the camera rays: the literal test of the tile's candidates, lowest index first
+            // ---- Trace() of the camera rays: the literal test of the tile's candidates, lowest index first --
+            // in the wave's first frame; a pixel's camera ray is the same ray in every frame, and so is its hit
             camera_pass = false;
-            for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
-                const int i = (int)__builtin_ctzll(todo);
-                bool far_root = false;
-                if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
-                const float4 g = smem[2 * i];
-                if (alive) test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
+            if (MANY && have_cam) {
+                best = cam_t;
+                idx = cam_idx;
+            } else {
+                for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
+                    const int i = (int)__builtin_ctzll(todo);
+                    bool far_root = false;
+                    if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
+                    const float4 g = smem[2 * i];
+                    if (alive) test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
+                }
+                cam_t = best;
+                cam_idx = idx;
+                have_cam = true;
             }
         } else if (__popcll(alive_mask) <= RT_LITE_TEAM_MAX) {  // wave-uniform
             // ---- Trace() of the few rays left, one after the other, a sphere per lane
