@@ -380,7 +380,7 @@ def interactive_ubos(rt, n):
 
 
 def interactive(args, rank, world, device, backend, torch, dist, rt):
-    from raytracing_amd.multi_gpu import InteractiveLoop, TileSplit
+    from raytracing_amd.multi_gpu import DirectTileLoop, InteractiveLoop, PeerImages, SharedFrameFlags, TileSplit
 
     wl = WORKLOADS["interactive"]
     w, h = wl["size"]
@@ -402,11 +402,51 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
             hosts[k].copy_(colors[k])
         return hosts[k] if staged else colors[k]
 
+    # The exchange of a frame.  "ipc": every rank's kernel writes its band straight into rank 0's colour images
+    # (mapped into every process), and a counter in shared host memory says when; "nccl": the bands are sent to
+    # rank 0 after the frame.  RT_BENCH_GATHER picks; "ipc" falls back to "nccl" when a rank cannot map the images.
+    exchange = "none"
+    direct = None
+    if world > 1:
+        exchange = os.environ.get("RT_BENCH_GATHER", "ipc")
+        if exchange == "ipc":
+            box, ok = [None], 1
+            try:
+                if rank == 0:
+                    direct = (PeerImages(0, 0, device, w * h * 4), SharedFrameFlags(world), SharedFrameFlags(1))
+                    box[0] = (direct[0].handles, direct[1].name, direct[2].name)
+            except Exception as e:  # noqa: BLE001 -- any failure means "use the transfer instead"
+                print(f"bench.py: rank 0 cannot export its colour images ({e})", file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            try:
+                if rank != 0 and box[0] is not None:
+                    direct = (PeerImages(rank, 0, device, w * h * 4, box[0][0]), SharedFrameFlags(world, box[0][1]),
+                              SharedFrameFlags(1, box[0][2]))
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: rank {rank} cannot map rank 0's colour images ({e})", file=sys.stderr)
+            ok = torch.tensor([1 if direct is not None else 0], device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:  # every rank takes this branch together
+                exchange = "nccl"
+                if direct is not None and rank != 0:
+                    direct[0].close()
+                dist.barrier()
+                if direct is not None:
+                    if rank == 0:
+                        direct[0].close()
+                    direct[1].close()
+                    direct[2].close()
+                direct = None
+
     # Kernel time: two HIP events on the context's stream around the whole timed region (the launches run back
     # to back, two frames in flight, so region / launches bounds a launch from above).  Events around every
     # launch cost ~9 us of a ~45 us frame and, queued behind the previous launch, time its tail too.
-    loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers_next(accum.data_ptr(), colors[k].data_ptr()), image_of,
-                           transfer_stream=(lambda: torch.cuda.current_stream().cuda_stream) if world > 1 and not staged else None)
+    if exchange == "ipc":
+        images, flags, shown = direct
+        loop = DirectTileLoop(tiles, r, lambda k: r.bind_buffers_next(accum.data_ptr(), images.ptrs[k]), flags, shown)
+    else:
+        loop = InteractiveLoop(tiles, r, lambda k: r.bind_buffers_next(accum.data_ptr(), colors[k].data_ptr()), image_of,
+                               transfer_stream=(lambda: torch.cuda.current_stream().cuda_stream) if world > 1 and not staged else None)
     for i in range(args.warmup):
         loop.frame(ubos[i])
     loop.finish()
@@ -448,8 +488,12 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
                             "Scene::update (the camera moves a unit and rests: the accumulation restarts in about 14 "
                             "frames of 40), uniforms set and dispatch issued per frame",
                 "parallelism": f"bands of 8x8-tile rows over {world} GPU(s); two frames in flight: frame f+1 is dispatched "
-                               "before the host waits for frame f, whose rgba8 bands are then gathered to rank 0 (two "
-                               "colour images); kernel time = HIP events around the timed region / launches",
+                               "before the host waits for frame f; exchange = " +
+                               {"none": "none (one GPU)",
+                                "ipc": "ipc: every rank's kernel writes its band into rank 0's two colour images (mapped into "
+                                       "every process), a counter in shared host memory per rank says when",
+                                "nccl": "nccl: the rgba8 bands of a frame are sent to rank 0 after it (two colour images)"}[exchange] +
+                               "; kernel time = HIP events around the timed region / launches",
                 "launch": f"{info['blocks']} x {info['threads']}",
             },
             "rays_per_second": float(stats[1]) / elapsed,
@@ -463,6 +507,15 @@ def interactive(args, rank, world, device, backend, torch, dist, rt):
             line["cpu_baseline"] = cpu_baseline(scene, (w, h), profile, args.max_depth, args.cpu_seconds,
                                                 interactive_frames=ubos[args.warmup:])
     r.close()
+    if exchange == "ipc":  # openers unmap before the owner frees
+        dist.barrier()
+        if rank != 0:
+            direct[0].close()
+        dist.barrier()
+        if rank == 0:
+            direct[0].close()
+        direct[1].close()
+        direct[2].close()
     return line
 
 

@@ -233,6 +233,24 @@ int rt_sync_dispatch(rt_context* ctx, int back);
 int rt_wait_stream(rt_context* ctx, void* hip_stream);
 int rt_stream_wait(rt_context* ctx, void* hip_stream);
 
+/* Device memory that the other processes of a node can map, for the screen-tile split: every GPU's
+   kernel writes its band of rows straight into the display GPU's colour image over xGMI instead of
+   sending it there afterwards.  No reference counterpart (the reference is one process, one GPU);
+   the nearest thing is the swap-chain image every frame is written into (compute_pipeline.cpp:589-655).
+     rt_ipc_alloc  allocates `bytes` on `device` (zeroed) and fills handle64 with the 64 bytes that
+                   another process passes to rt_ipc_open;
+     rt_ipc_open   maps the allocation behind handle64 into this process for kernels on `device`
+                   (the same device as the owner's, or a peer of it); the pointer is good for
+                   rt_bind_buffers / rt_bind_buffers_next;
+     rt_ipc_close  unmaps it (every opener, before the owner frees); rt_ipc_free frees the owner's.
+   What the runtime guarantees: a kernel's writes into a mapped peer allocation are in the
+   owner's memory once the writer's host has seen that kernel complete (rt_sync, rt_sync_dispatch). */
+#define RT_IPC_HANDLE_BYTES 64
+int rt_ipc_alloc(int device, size_t bytes, void** dev_ptr, void* handle64);
+int rt_ipc_open(int device, const void* handle64, void** dev_ptr);
+int rt_ipc_close(int device, void* dev_ptr);
+int rt_ipc_free(int device, void* dev_ptr);
+
 /* Re-resolve the colour image from the accumulation image with an explicit
    divisor: colour = unorm8(accum.rgb / divisor)  (shader.comp:129-132), used
    after a cross-GPU sum. */

@@ -62,6 +62,10 @@ SIGNATURES = {
     "rt_wait_stream": (C.c_int, [_P, _P]),
     "rt_stream_wait": (C.c_int, [_P, _P]),
     "rt_resolve": (C.c_int, [_P, C.c_float]),
+    "rt_ipc_alloc": (C.c_int, [C.c_int, C.c_size_t, _PP, _P]),
+    "rt_ipc_open": (C.c_int, [C.c_int, _P, _PP]),
+    "rt_ipc_close": (C.c_int, [C.c_int, _P]),
+    "rt_ipc_free": (C.c_int, [C.c_int, _P]),
     "rt_trace_crop": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rt_get_counters": (C.c_int, [_P, C.POINTER(Counters)]),
     "rt_reset_counters": (C.c_int, [_P]),

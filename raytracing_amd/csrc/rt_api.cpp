@@ -1306,6 +1306,58 @@ int rt_stream_wait(rt_context* c, void* hip_stream)
     return order_streams(c, c->stream, static_cast<hipStream_t>(hip_stream));
 }
 
+static_assert(sizeof(hipIpcMemHandle_t) == RT_IPC_HANDLE_BYTES, "rt_hip.h promises a 64-byte handle");
+
+int rt_ipc_alloc(int device, size_t bytes, void** dev_ptr, void* handle64)
+{
+    if (!dev_ptr || !handle64 || bytes == 0) return fail(RT_E_INVALID, "bad argument");
+    *dev_ptr = nullptr;
+    RtDeviceGuard guard_(device);
+    if (guard_.status() != hipSuccess) return fail(RT_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(guard_.status()));
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    hipIpcMemHandle_t h;
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(RT_E_HIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    }
+    memcpy(handle64, &h, sizeof h);
+    *dev_ptr = p;
+    return RT_OK;
+}
+
+int rt_ipc_open(int device, const void* handle64, void** dev_ptr)
+{
+    if (!dev_ptr || !handle64) return fail(RT_E_INVALID, "bad argument");
+    *dev_ptr = nullptr;
+    RtDeviceGuard guard_(device);
+    if (guard_.status() != hipSuccess) return fail(RT_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(guard_.status()));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof h);
+    HIP_TRY(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return RT_OK;
+}
+
+int rt_ipc_close(int device, void* dev_ptr)
+{
+    if (!dev_ptr) return RT_OK;
+    RtDeviceGuard guard_(device);
+    if (guard_.status() != hipSuccess) return fail(RT_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(guard_.status()));
+    HIP_TRY(hipIpcCloseMemHandle(dev_ptr));
+    return RT_OK;
+}
+
+int rt_ipc_free(int device, void* dev_ptr)
+{
+    if (!dev_ptr) return RT_OK;
+    RtDeviceGuard guard_(device);
+    if (guard_.status() != hipSuccess) return fail(RT_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(guard_.status()));
+    HIP_TRY(hipFree(dev_ptr));
+    return RT_OK;
+}
+
 int rt_dispatch_frames_timed(rt_context* c, int n_frames)
 {
     if (!c) return fail(RT_E_INVALID, "ctx is null");

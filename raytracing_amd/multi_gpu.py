@@ -183,3 +183,135 @@ class InteractiveLoop:
             self.renderer.sync()
             self._deliver(self.count - 1)
             self.count = 0
+
+
+class SharedFrameFlags:
+    """Frame counters that the processes of one node share through POSIX shared memory: slot g
+    holds the number of frames whose band rank g's HOST has seen complete.  Plain host stores and
+    loads -- no collective, no device-side spinning; a wait that lasts longer than `timeout`
+    seconds raises instead of hanging."""
+
+    def __init__(self, world: int, name: str | None = None, timeout: float = 30.0):
+        from multiprocessing import shared_memory
+
+        import numpy as np
+
+        self.world, self.timeout = world, timeout
+        self.owner = name is None
+        self.shm = shared_memory.SharedMemory(create=True, size=64 * world) if self.owner \
+            else shared_memory.SharedMemory(name=name)
+        # one counter per cache line
+        self.done = np.ndarray((world, 8), dtype=np.int64, buffer=self.shm.buf)[:, 0]
+        if self.owner:
+            self.done[:] = 0
+
+    @property
+    def name(self) -> str:
+        return self.shm.name
+
+    def publish(self, rank: int, frames_done: int) -> None:
+        self.done[rank] = frames_done
+
+    def wait_all(self, frames_done: int, ranks) -> None:
+        import time
+
+        t0 = None
+        for g in ranks:
+            while int(self.done[g]) < frames_done:
+                if t0 is None:
+                    t0 = time.monotonic()
+                elif time.monotonic() - t0 > self.timeout:
+                    raise TimeoutError(f"rank {g} has not finished frame {frames_done} after {self.timeout} s")
+
+    def close(self) -> None:
+        self.done = None
+        self.shm.close()
+        if self.owner:
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
+
+
+class PeerImages:
+    """The display rank's two colour images, mapped into every rank of the node (rt_ipc_alloc /
+    rt_ipc_open): each rank's kernel writes its band of rows straight into them over xGMI."""
+
+    def __init__(self, rank: int, dst: int, device: int, nbytes: int, handles=None):
+        import ctypes as C
+
+        from . import _native as N
+
+        self.rank, self.dst, self.device, self.nbytes = rank, dst, device, nbytes
+        self.owner = rank == dst
+        self.ptrs, self.handles = [], []
+        for k in range(2):
+            p = C.c_void_p()
+            if self.owner:
+                h = C.create_string_buffer(64)
+                N.check(N.lib().rt_ipc_alloc(device, nbytes, C.byref(p), h))
+                self.handles.append(h.raw)
+            else:
+                N.check(N.lib().rt_ipc_open(device, handles[k], C.byref(p)))
+            self.ptrs.append(p.value)
+
+    def close(self) -> None:
+        from . import _native as N
+
+        for p in self.ptrs:
+            N.check((N.lib().rt_ipc_free if self.owner else N.lib().rt_ipc_close)(self.device, p))
+        self.ptrs = []
+
+
+class DirectTileLoop:
+    """The interactive tile split without a transfer: every rank's kernel writes its band into the
+    display rank's colour image (PeerImages), and what is exchanged per frame is a counter in
+    shared host memory (SharedFrameFlags).  Two frames in flight as in InteractiveLoop: frame f is
+    dispatched before the host waits for frame f-1.
+
+    Order of events that makes the displayed frame whole and its own:
+      * rank g publishes "f frames done" only after ITS HOST has seen the dispatch of frame f-1
+        complete (Renderer.sync_dispatch), which is when that kernel's writes are in the display
+        GPU's memory;
+      * the display rank shows frame f-1 once every rank with a band has published it, and then
+        publishes "f frames shown";
+      * image f % 2 is written again by frame f + 2, which a rank dispatches only after the
+        display rank has shown frame f (`shown` counter), so a frame on display is never written.
+    `on_frame(f, k)` is called on the display rank, in order, with the frame number and the image
+    index; it must have finished READING image k when it returns.
+    """
+
+    def __init__(self, tiles: TileSplit, renderer, bind_color, flags: SharedFrameFlags, shown: SharedFrameFlags,
+                 on_frame=None, dst: int = 0, dispatch=None):
+        self.tiles, self.renderer, self.bind_color = tiles, renderer, bind_color
+        self.flags, self.shown, self.on_frame, self.dst = flags, shown, on_frame, dst
+        self.dispatch = dispatch or (lambda: renderer.dispatch(1))
+        self.writers = [g for g, (r0, r1) in enumerate(tiles.bands) if r1 > r0]
+        self.count = 0
+
+    def _finished(self, f: int) -> None:
+        """Frame f (0-based) is complete on this rank's GPU."""
+        self.flags.publish(self.tiles.rank, f + 1)
+        if self.tiles.rank == self.dst:
+            self.flags.wait_all(f + 1, self.writers)
+            if self.on_frame is not None:
+                self.on_frame(f, f % 2)
+            self.shown.publish(0, f + 1)
+
+    def frame(self, ubo) -> None:
+        f = self.count
+        if f >= 2:
+            self.shown.wait_all(f - 1, [0])  # frame f-2, the last to use image f % 2, has been shown
+        self.bind_color(f % 2)
+        self.renderer.set_uniforms(ubo)
+        self.dispatch()
+        if f > 0:
+            self.renderer.sync_dispatch(1)  # frame f-1 is complete; frame f is being traced
+            self._finished(f - 1)
+        self.count = f + 1
+
+    def finish(self) -> None:
+        if self.count > 0:
+            self.renderer.sync()
+            self._finished(self.count - 1)
+            self.count = 0

@@ -123,6 +123,18 @@ def test_bench_two_ranks_rehearsal(workload, launcher):
         assert line["scaling"] == "weak" and line["unit"] == "Mrays/s"
     else:
         assert line["unit"] == "ms" and line["higher_is_better"] is False and line["scaling"] == "strong"
+        assert "exchange = ipc" in line["config"]["parallelism"]  # the two ranks map rank 0's images (one device here)
+
+
+def test_bench_interactive_two_ranks_with_the_nccl_style_gather():
+    """The fallback exchange of the interactive workload (bands sent to rank 0 after every frame), rehearsed with gloo."""
+    env = dict(os.environ, RT_BENCH_DEVICE="0", RT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", RT_BENCH_GATHER="nccl")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0",
+                          "--workload", "interactive"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = _one_json_line(res.stdout)
+    assert line["n_gpus"] == 2 and "exchange = nccl" in line["config"]["parallelism"]
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
