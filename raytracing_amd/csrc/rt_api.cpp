@@ -773,6 +773,13 @@ void use_frame_split(rt_context* c, RtParams& P)
     const unsigned ntiles = P.total_pixels / 64u;
     const unsigned slots = 20u * (unsigned)c->cu_count;  // waves of this kernel that the chip holds at a time
     int ways = 2 * ntiles < 3 * slots ? 8 : 2 * ntiles < 9 * slots ? 4 : 2;
+    // two runs whose lights would have to be parked in device memory, where four runs' lights fit in LDS (below):
+    // four, up to images of 20 tiles per wave slot (measured at 64 frames, 2 ways parked against 4 through LDS:
+    // 1920x1080 119 -> 124 Grays/s, 2560x1440 127 -> 132, 3840x2160 146 -> 141)
+    auto fits_lds = [&](int w) {
+        return rt_lite_handover_bytes(4u, w, (P.n_frames + w - 1) / w) <= (size_t)9216 * 4u;
+    };
+    if (ways == 2 && !fits_lds(2) && fits_lds(4) && ntiles < 20u * slots) ways = 4;
     if (ways_env == 2 || ways_env == 4 || ways_env == 8) ways = ways_env;
     const int frames = (P.n_frames + ways - 1) / ways;
     // Where the lights of a tile's later runs fit in LDS beside four workgroups' worth of everything else (9 KiB a

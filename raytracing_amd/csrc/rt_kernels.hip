@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     float* lds_lights = nullptr;  // this tile's entries, at this lane
     if (lds_handover && run >= 0)
         lds_lights = reinterpret_cast<float*>(lgeom + 2 * RT_CHUNK) +
-                     (size_t)((threadIdx.x >> 6) / ways) * (ways - 1u) * (size_t)P.split_frames * 192u + lane;
+                     (size_t)((threadIdx.x >> 6) / (MANY ? ways : 1u)) * (ways - 1u) * (size_t)P.split_frames * 192u + lane;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (run <= 0 && !clear_at(P, 0, P.frame0)) acc = P.accum[at];
     float d0x, d0y, d0z;
@@ -1242,12 +1242,39 @@ __device__ __forceinline__ void mfma_tile(v8bf a0, v8bf a1, const MfmaRay& r, in
 // instructions that read the current tile's accumulators, so that a wave keeps both pipes busy
 // by itself.  Writes the candidate masks of the chunks to wmask[c * 64 + lane] and returns the
 // summary (bit 31 - c set when chunk c has a candidate for this lane).
-template <bool BEHIND>
+// PIPE = false: one tile at a time, 32 accumulator registers instead of 64 -- for the launch with three
+// waves per SIMD (168 registers a lane), where the other waves cover the wait for the matrix pipe and the
+// pipelined loop made the compiler park a lane's per-pixel state in scratch memory around it (measured at
+// 484 spheres: 24.4 against 23.9 Grays/s; with two waves per SIMD, 1000 spheres, the pipelined loop wins by 3 %).
+template <bool BEHIND, bool PIPE>
 __device__ __forceinline__ uint32_t sieve_chunks_mfma(const v8bf* frag, int nsg, int lane, const MfmaRay& r,
                                                       bool alive, bool has_last, uint32_t last_valid,
                                                       uint32_t* wmask)
 {
     uint32_t summary = 0;
+    if constexpr (!PIPE) {
+    v8bf a0 = frag[lane], a1 = frag[64 + lane];
+    for (int c = 0; c < nsg; c++) {
+        const int cn = min(c + 1, nsg - 1);
+        const v8bf n0 = frag[cn * 128 + lane], n1 = frag[cn * 128 + 64 + lane];
+        v16f S, T;
+        mfma_tile(a0, a1, r, 0, S, T);
+        const uint32_t m0 = tile_mask<BEHIND>(S, T);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(a0, a1, r, 1, S, T);
+        const uint32_t m1 = tile_mask<BEHIND>(S, T);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0;
+        a1 = n1;
+        const v2u own = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
+        uint32_t cand = ~((own.x << 16) | own.y);
+        if (has_last && c == nsg - 1) cand &= last_valid;
+        if (!alive) cand = 0u;
+        wmask[c * 64 + lane] = cand;
+        summary = (summary << 1) | (cand != 0u ? 1u : 0u);
+    }
+    return summary << (32 - nsg);
+    }
     v16f SA, TA, SB, TB;
     v8bf a0 = frag[lane], a1 = frag[64 + lane];
     mfma_tile(a0, a1, r, 0, SA, TA);
@@ -1804,11 +1831,12 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 #define RT_CAM_UNKNOWN (-2)
 
 template <bool FUSED, bool RECORD, int MODE>
-__global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
+__global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
 {
     constexpr bool SGEOM = MODE == 1 || MODE == 2;
     constexpr bool CULL = MODE == 2;
-    constexpr bool MFMA = MODE == 3 || MODE == 5;
+    constexpr bool MFMA = MODE == 3 || MODE == 5 || MODE == 7;
+    constexpr bool PIPE = MODE != 7;  // 7 = 3 for workgroups of more than RT_STREAM_MAX_THREADS threads (three waves per SIMD)
     constexpr bool FAR_FRAGS = MODE == 5;  // matrix-core sieve with its sphere-side operands left in global memory
     constexpr bool BVH = MODE == 4;
     constexpr bool BVH_FAR = MODE == 6;  // per-lane traversal out of global memory (nothing staged: P.n_lds == 0)
@@ -2100,8 +2128,8 @@ __global__ void __launch_bounds__(MODE == 3 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                 } else if constexpr (MFMA) {
                     const v8bf* fr = reinterpret_cast<const v8bf*>(frags) + sg * 128;
                     summary = P.materials == nullptr
-                                  ? sieve_chunks_mfma<true>(fr, nsg, lane, mr, tracing, sg + nsg == nch, P.last_chunk_valid, wmask)
-                                  : sieve_chunks_mfma<false>(fr, nsg, lane, mr, tracing, sg + nsg == nch, P.last_chunk_valid, wmask);
+                                  ? sieve_chunks_mfma<true, PIPE>(fr, nsg, lane, mr, tracing, sg + nsg == nch, P.last_chunk_valid, wmask)
+                                  : sieve_chunks_mfma<false, PIPE>(fr, nsg, lane, mr, tracing, sg + nsg == nch, P.last_chunk_valid, wmask);
                 } else {
                     for (int c = 0; c < nsg; c++) {
                         constexpr int GROUP = SGEOM ? RT_GROUP_SGPR : RT_GROUP_LDS;
@@ -2511,6 +2539,13 @@ hipError_t rt_launch_stream(const RtParams& P, bool fused, bool record, int mode
                          : launch_stream<false, true, 4>(P, blocks, threads, lds, st);
         return fused ? launch_stream<true, false, 4>(P, blocks, threads, lds, st)
                      : launch_stream<false, false, 4>(P, blocks, threads, lds, st);
+    }
+    if (mode == 3 && threads > RT_STREAM_MAX_THREADS) {  // three waves per SIMD: the instantiation that keeps within 168 registers
+        if (record)
+            return fused ? launch_stream<true, true, 7>(P, blocks, threads, lds, st)
+                         : launch_stream<false, true, 7>(P, blocks, threads, lds, st);
+        return fused ? launch_stream<true, false, 7>(P, blocks, threads, lds, st)
+                     : launch_stream<false, false, 7>(P, blocks, threads, lds, st);
     }
     if (mode == 3) {
         if (record)

@@ -36,4 +36,17 @@ timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 # the unprofiled line of the same command, for the record next to the profiled one
 timeout -k 10 300 python3 bench.py $args > "$out/bench_plain.log" 2>&1
 grep '^{' "$out/bench_plain.log" > "$out/bench_line_plain.json"
+# clock and power under load: the same command with enough steps to last some seconds, the device sampled meanwhile
+# (rocm-smi, read-only: shader clock and socket power), to set the counter-derived clock beside what the part reports
+steps=600; case "$wl" in interactive) steps=60000;; default720p_d8) steps=4000;; default1080p) steps=2500;; esac
+timeout -k 10 200 python3 bench.py $args --steps $steps > "$out/bench_long.log" 2>&1 &
+pid=$!
+: > "$out/smi_samples.jsonl"
+while kill -0 $pid 2>/dev/null; do
+  timeout 5 rocm-smi -d 0 -c -P --json >> "$out/smi_samples.jsonl" 2>/dev/null || true
+  echo >> "$out/smi_samples.jsonl"
+  sleep 0.4
+done
+wait $pid || echo "long run failed (optional)"
+grep '^{' "$out/bench_long.log" > "$out/bench_line_long.json" || true
 echo "collected $label"

@@ -44,6 +44,46 @@ def per_launch(path, timed):
     return out, dur, (rows[0]["Kernel_Name"].split("(")[0] if rows else None)
 
 
+def smi_under_load(path):
+    """Shader clock (MHz) and socket power (W) that rocm-smi reported while a long run of the workload was
+    going: the samples taken once the clock had left its idle value, median and extremes."""
+    import re
+    import statistics
+
+    if not os.path.exists(path):
+        return None
+    clocks, power = [], []
+    for ln in open(path):
+        ln = ln.strip()
+        if not ln.startswith("{"):
+            continue
+        try:
+            card = next(iter(json.loads(ln).values()))
+        except Exception:
+            continue
+        for k, v in card.items():
+            m = re.search(r"\((\d+)Mhz\)", str(v))
+            if "sclk" in k.lower() and m:
+                clocks.append(int(m.group(1)))
+            if "power" in k.lower() and "(w)" in k.lower():
+                try:
+                    power.append(float(v))
+                except ValueError:
+                    pass
+    busy = [(c, p) for c, p in zip(clocks, power)] if len(clocks) == len(power) else [(c, None) for c in clocks]
+    if power:
+        busy = [(c, p) for c, p in busy if p is not None and p > 0.5 * max(power)] or busy
+    elif clocks:  # no power reading for this user: the samples whose clock has left the idle value
+        busy = [(c, None) for c in clocks if c > 0.5 * max(clocks)]
+    if not busy:
+        return None
+    cs = [c for c, _ in busy]
+    ps = [p for _, p in busy if p is not None]
+    return {"samples": len(busy), "sclk_mhz_median": statistics.median(cs), "sclk_mhz_min": min(cs), "sclk_mhz_max": max(cs),
+            "power_w_median": statistics.median(ps) if ps else None, "power_w_max": max(ps) if ps else None,
+            "how": "rocm-smi -c -P every ~0.7 s during a run of the same command with more steps; samples above half the peak power (or, without a power reading, half the peak clock)"}
+
+
 def one(tag, wl, pmc_all):
     src = os.path.join(ROOT, "gpurun_out", "prof", tag, wl)
     dst = os.path.join(ROOT, "profiles")
@@ -107,6 +147,11 @@ def one(tag, wl, pmc_all):
             out["rocprof_calls"] = int(r["Calls"])
             break
     out["kernel_ms_per_launch_bench"] = line["roofline"]["kernel_ms_per_launch"]
+    smi = smi_under_load(os.path.join(src, "smi_samples.jsonl"))
+    if smi:
+        out["smi_under_load"] = smi
+        if "clock_ghz" in out:
+            out["fp32_peak_at_counter_clock_tflops"] = PEAK_TFLOPS * out["clock_ghz"] / 2.4
     pmc_all[key] = out
     print(wl, json.dumps(out, indent=1))
 
