@@ -714,15 +714,16 @@ __device__ __forceinline__ bool tile_cone_keeps(float ox, float oy, float oz, fl
 
 // MANY = false: the instantiation for dispatches of one frame (the interactive loop), without the
 // code for going from frame to frame and for runs of frames (measured: 48 against 52 us per 1080p frame).
+// (one frame per dispatch is bound by latency, not by issue: its instantiation is held to 80 registers, six waves
+// per SIMD instead of five -- 1920x1080 x 1 frame 47.5 -> 45.4 us; the many-frame one would spill at that and is
+// held to 96 registers, five waves)
 template <bool FUSED, bool MANY>
-__global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY ? 5 : 6, MANY ? 5 : 6))) rt_lite_kernel(const RtParams P)
 {
     extern __shared__ float4 smem[];
     float4* lgeom = smem + 2 * 2 * RT_CHUNK;
-    for (int i = threadIdx.x; i < 2 * P.sphere_count; i += blockDim.x)
-        smem[i] = reinterpret_cast<const float4*>(P.spheres)[i];
-    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
-    __syncthreads();
+    // (the wave's tile and its texel are fetched first, two dependent loads from global memory, so that they are
+    // on their way while the workgroup copies the scene into LDS below: 1920x1080 x 1 frame 47 -> XX us)
     uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     // The first split_tiles tiles of the order, the heaviest, go to split_ways waves each (below): wave
     // `run` of a tile traces the frames [run, run + 1) * split_frames of the dispatch.  run < 0: all frames.
@@ -740,7 +741,6 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     // (a wave beyond the last tile stays for the barrier of the runs' hand-over through LDS and does nothing else)
     const bool valid = slot < (uint32_t)P.tile_cols * (uint32_t)P.tile_rows;  // wave-uniform
     if (!valid) {
-        if (!MANY || P.split_lds == 0) return;
         slot = 0;
         run = -1;
     }
@@ -769,6 +769,13 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     if (run <= 0 && !clear_at(P, 0, P.frame0)) acc = P.accum[at];
     float d0x, d0y, d0z;
     primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
+
+    // the workgroup's copy of the sphere records and of the sieve geometry
+    for (int i = threadIdx.x; i < 2 * P.sphere_count; i += blockDim.x)
+        smem[i] = reinterpret_cast<const float4*>(P.spheres)[i];
+    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
+    __syncthreads();
+    if (!valid && (!MANY || P.split_lds == 0)) return;
     const bool two = P.n_pad > RT_CHUNK;                   // one or two chunks of 32 spheres
     const uint32_t valid0 = two ? 0xffffffffu : P.n_pad ? P.last_chunk_valid : 0u;  // empty scene: no candidates
     const uint32_t valid1 = two ? P.last_chunk_valid : 0u;
@@ -948,7 +955,11 @@ __global__ void __launch_bounds__(1024) rt_lite_kernel(const RtParams P)
     }
     if (!valid) return;
     // (every camera ray of this kernel is traced against its tile's list: the host counts them, a path each)
+#ifdef RT_LITE_NO_COUNT
+    const unsigned long long wave_rays = nrays;
+#else
     const unsigned long long wave_rays = add_rays(P, nrays, tile);
+#endif
     // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
     if (P.tile_cost != nullptr && lane == 0 && run <= 0)
         P.tile_cost[tile] = (uint32_t)min(wave_rays * (run == 0 ? ways : 1u), 0xffffffffull);
