@@ -338,7 +338,7 @@ int rt_debug_fail_next_launch(rt_context* ctx);
    speed of RT_KERNEL_STREAM_LDS above 64 spheres (the vector-ALU sieve, no camera-ray hits kept
    between calls, spans in image order: about half the rate of a context's default kernel on a
    484-sphere scene), because the device memory a context would own (work-queue counters, ray
-   counters, repacked sieve geometry) is a static device array inside the library, about 100 KiB
+   counters, repacked sieve geometry) is a static device array inside the library, about 128 KiB
    per GPU, held until the process ends.  Inputs and outputs are the caller's:
      spheres_aos32_dev  DEVICE pointer to n_spheres 32-byte spheres (includes/scene.hpp:31-36),
                         n_spheres <= RT_STATIC_MAX_SPHERES (larger scenes are rejected with

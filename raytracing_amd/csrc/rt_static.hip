@@ -28,7 +28,7 @@ static_assert(RT_STATIC_MAX_SPHERES % RT_CHUNK == 0 && RT_STATIC_MAX_SPHERES <= 
 
 }  // namespace
 
-// 100 KiB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the
+// 128 KiB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the
 // address the kernels get is the one looked up per device in static_setup().
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
@@ -63,7 +63,8 @@ __global__ void rt_static_pack_kernel(const RtSphereAos* aos, int n_spheres, int
 // Sum of the ray-counter slots -> *out (one wave).
 __global__ void rt_static_sum_rays_kernel(const unsigned long long* slots, unsigned long long* out)
 {
-    unsigned long long v = threadIdx.x < RT_RAY_SLOTS ? slots[threadIdx.x * RT_RAY_SLOT_STRIDE] : 0ull;
+    unsigned long long v = 0ull;
+    for (unsigned i = threadIdx.x; i < RT_RAY_SLOTS; i += 64u) v += slots[i * RT_RAY_SLOT_STRIDE];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (threadIdx.x == 0) *out = v;
