@@ -718,7 +718,7 @@ __device__ __forceinline__ bool tile_cone_keeps(float ox, float oy, float oz, fl
 // per SIMD instead of five -- 1920x1080 x 1 frame 47.5 -> 45.4 us; the many-frame one would spill at that and is
 // held to 96 registers, five waves)
 template <bool FUSED, bool MANY>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY ? 5 : 6, MANY ? 5 : 6))) rt_lite_kernel(const RtParams P)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY ? 4 : 6, MANY ? 5 : 6))) rt_lite_kernel(const RtParams P)
 {
     extern __shared__ float4 smem[];
     float4* lgeom = smem + 2 * 2 * RT_CHUNK;
@@ -818,22 +818,63 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
     const bool bundle = P.cam_reuse != 0;  // off: camera rays go through the sieve like every other ray
     bool camera_pass = bundle;  // every live lane is on the camera ray of its pixel: the first pass of every frame
 
-    bool waiting = false;  // the lane's path of this frame has ended, the next frame's is set up
     bool have_cam = false;  // wave-uniform: cam_idx, cam_t hold the hit of the lane's camera ray
     int cam_idx = -1;
     float cam_t = RT_FLT_MAX;
+    // The end of a path: its light goes to the texel (or, in a run after a tile's first, to where the first run
+    // will find it), and the lane goes on to its next frame or is done.
+#define RT_LITE_END_PATH                                                                                        \
+    {                                                                                                           \
+        if (MANY && lights != nullptr) {                                                                        \
+            lights[(size_t)(j - j_begin) * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);                            \
+        } else if (MANY && lds_handover && run > 0) {                                                           \
+            float* at_l = lds_lights + (size_t)(j - P.split_frames) * 192u; /* run r, frame k: (r - 1) * split_frames + k */ \
+            at_l[0] = p.lr;                                                                                     \
+            at_l[64] = p.lg;                                                                                    \
+            at_l[128] = p.lb;                                                                                   \
+        } else {                                                                                                \
+            acc.x = p.lr + acc.x; /* vec4(light, 1.0) + accumulated */                                          \
+            acc.y = p.lg + acc.y;                                                                               \
+            acc.z = p.lb + acc.z;                                                                               \
+            acc.w = 1.0f + acc.w;                                                                               \
+        }                                                                                                       \
+        j++;                                                                                                    \
+        if (!MANY || j == j_end) {                                                                              \
+            alive = false;                                                                                      \
+        } else {                                                                                                \
+            frame = P.frame0 + (uint32_t)(j * P.frame_stride);                                                  \
+            if (clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+            path_reset(p, P, d0x, d0y, d0z);                                                                    \
+        }                                                                                                       \
+    }
     for (;;) {
-        const unsigned long long alive_mask = __ballot(alive);
-        if (alive_mask == 0ull) {
-            // the frame is done in every lane: on to the next one, all camera rays together again
-            if (!MANY || __ballot(waiting) == 0ull) break;
-            if (waiting) {
-                alive = true;
-                waiting = false;
+        // ---- a lane at the start of a frame whose camera hit is known shades it and joins the others with its
+        // first bounce ray: after the wave's first pass no lane waits for another, each runs through its frames at
+        // its own pace (a pass of sieve and walk costs the same whatever the number of rays in it, and per frame
+        // the slowest path of 64 is several times the average one).  A pixel that sees the sky is finished at
+        // once, all its frames.  (More than one turn of the inner loop only at depth 1.)
+        if constexpr (MANY) {
+            if (have_cam) {  // wave-uniform
+                while (__ballot(alive && p.bounce == 0) != 0ull) {
+                    if (alive && p.bounce == 0) {
+                        if (cam_idx < 0) {
+                            (void)path_bounce<FUSED, false>(p, P, -1, RT_FLT_MAX, px, py, frame, nullptr, smem);
+                            const float sr = p.lr, sg = p.lg, sb = p.lb;
+                            nrays += (unsigned)(j_end - j);
+                            while (alive) {
+                                p.lr = sr; p.lg = sg; p.lb = sb;
+                                RT_LITE_END_PATH
+                            }
+                        } else {
+                            nrays++;
+                            if (path_bounce<FUSED, false>(p, P, cam_idx, cam_t, px, py, frame, nullptr, smem)) RT_LITE_END_PATH
+                        }
+                    }
+                }
             }
-            camera_pass = bundle;
-            continue;
         }
+        const unsigned long long alive_mask = __ballot(alive);
+        if (alive_mask == 0ull) break;
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
         int idx = -1;
@@ -841,21 +882,16 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
             // ---- Trace() of the camera rays: the literal test of the tile's candidates, lowest index first --
             // in the wave's first frame; a pixel's camera ray is the same ray in every frame, and so is its hit
             camera_pass = false;
-            if (MANY && have_cam) {
-                best = cam_t;
-                idx = cam_idx;
-            } else {
-                for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
-                    const int i = (int)__builtin_ctzll(todo);
-                    bool far_root = false;
-                    if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
-                    const float4 g = smem[2 * i];
-                    if (alive) test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
-                }
-                cam_t = best;
-                cam_idx = idx;
-                have_cam = true;
+            for (unsigned long long todo = tile_spheres; todo != 0ull; todo &= todo - 1ull) {
+                const int i = (int)__builtin_ctzll(todo);
+                bool far_root = false;
+                if (P.materials != nullptr) far_root = P.materials[i].x == 3.0f;
+                const float4 g = smem[2 * i];
+                if (alive) test_sphere<FUSED>(p, a, g.x, g.y, g.z, g.w, i, best, idx, far_root);
             }
+            cam_t = best;
+            cam_idx = idx;
+            have_cam = true;
         } else if (__popcll(alive_mask) <= RT_LITE_TEAM_MAX) {  // wave-uniform
             // ---- Trace() of the few rays left, one after the other, a sphere per lane
             for (unsigned long long todo = alive_mask; todo != 0ull; todo &= todo - 1ull) {
@@ -904,36 +940,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
                 }
             }
         }
-        // ---- shade; a lane whose path has ended waits for the others with its next frame set up
+        // ---- shade; a lane whose path has ended goes on to its next frame
         if (alive) {
             nrays++;
-            if (path_bounce<FUSED, false>(p, P, idx, best, px, py, frame, nullptr, smem)) {
-                if (MANY && lights != nullptr) {
-                    lights[(size_t)(j - j_begin) * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);
-                } else if (MANY && lds_handover && run > 0) {
-                    float* at_l = lds_lights + (size_t)(j - P.split_frames) * 192u;  // run r, frame k of it: (r - 1) * split_frames + k
-                    at_l[0] = p.lr;
-                    at_l[64] = p.lg;
-                    at_l[128] = p.lb;
-                } else {
-                    acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
-                    acc.y = p.lg + acc.y;
-                    acc.z = p.lb + acc.z;
-                    acc.w = 1.0f + acc.w;
-                }
-                j++;
-                if (!MANY || j == j_end) {
-                    alive = false;
-                } else {
-                    frame = P.frame0 + (uint32_t)(j * P.frame_stride);
-                    if (clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    path_reset(p, P, d0x, d0y, d0z);
-                    alive = false;
-                    waiting = true;
-                }
-            }
+            if (path_bounce<FUSED, false>(p, P, idx, best, px, py, frame, nullptr, smem)) RT_LITE_END_PATH
         }
     }
+#undef RT_LITE_END_PATH
     if (lds_handover) {
         // the runs of a tile meet here: the first one adds the others' lights in frame order, as one wave tracing
         // all frames would have added them (float addition does not associate), and stores the pixel
