@@ -722,9 +722,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
 {
     extern __shared__ float4 smem[];
     float4* lgeom = smem + 2 * 2 * RT_CHUNK;
-    // (the wave's tile and its texel are fetched first, two dependent loads from global memory, so that they are
-    // on their way while the workgroup copies the scene into LDS below: 1920x1080 x 1 frame 47.9 -> 47.5 us)
-    uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // A wave of a one-frame dispatch lives a few microseconds, most of them waiting for memory: the loads of the
+    // workgroup's copy of the scene are issued first, then the wave's tile (through the scalar cache: the
+    // slot is wave-uniform) and its texel, and only then is anything waited for.
+    const float4* scene4 = reinterpret_cast<const float4*>(P.spheres);
+    const bool stage0 = (int)threadIdx.x < 2 * P.sphere_count, stage1 = (int)threadIdx.x < P.n_pad;
+    float4 staged0 = make_float4(0.f, 0.f, 0.f, 0.f), staged1 = staged0;
+    if (stage0) staged0 = scene4[threadIdx.x];
+    if (stage1) staged1 = P.geom[threadIdx.x];
+    uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // The first split_tiles tiles of the order, the heaviest, go to split_ways waves each (below): wave
     // `run` of a tile traces the frames [run, run + 1) * split_frames of the dispatch.  run < 0: all frames.
     int run = -1;
@@ -771,9 +777,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
     primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
 
     // the workgroup's copy of the sphere records and of the sieve geometry
-    for (int i = threadIdx.x; i < 2 * P.sphere_count; i += blockDim.x)
-        smem[i] = reinterpret_cast<const float4*>(P.spheres)[i];
-    for (int i = threadIdx.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
+    if (stage0) smem[threadIdx.x] = staged0;
+    if (stage1) lgeom[threadIdx.x] = staged1;
+    for (int i = threadIdx.x + blockDim.x; i < 2 * P.sphere_count; i += blockDim.x) smem[i] = scene4[i];
+    for (int i = threadIdx.x + blockDim.x; i < P.n_pad; i += blockDim.x) lgeom[i] = P.geom[i];
     __syncthreads();
     if (!valid && (!MANY || P.split_lds == 0)) return;
     const bool two = P.n_pad > RT_CHUNK;                   // one or two chunks of 32 spheres
