@@ -290,6 +290,11 @@ int rt_get_info(rt_context* ctx, int* device, int* cu_count, int* blocks, int* t
    4 the lite kernel (vector ALU, one wave per tile), 6 the per-lane traversal; -1 when the last dispatch ran the tile kernel or nothing has been dispatched.
    No reference counterpart. */
 int rt_get_sieve_mode(rt_context* ctx, int* mode);
+/* Test hook: how the last stream-kernel dispatch shared the frames of heavy tiles (image tiles whose pixels
+   bounce long in every frame) among several units of work: out = {units per heavy tile, frames per unit, most
+   tiles it would have split, tiles it did split}; all 0 when it did not.  Synchronises.  No reference
+   counterpart (the shader's invocations are scheduled by the driver). */
+int rt_debug_split_info(rt_context* ctx, int out[4]);
 
 /* Test hook: out[i] = op(a[i], b[i], c[i]) evaluated on the device with the kernels'
    compile flags, so the parity tests can pin the GPU's float semantics against the

@@ -76,6 +76,7 @@ SIGNATURES = {
     "rt_set_launch": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_get_info": (C.c_int, [_P] + [C.POINTER(C.c_int)] * 4),
     "rt_get_sieve_mode": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "rt_debug_split_info": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "rt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int]),
     "rt_debug_sieve_audit": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),
     "rt_debug_cull_audit": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64)]),

@@ -98,11 +98,16 @@ struct rt_context {
     unsigned hits_cap = 0;             // tiles d_cam_hits has room for
     bool hits_valid = false;           // d_cam_hits describes hits_key
     float hits_key[12 + 8] = {0};      // camera, image size, region, sphere count and float profile of that
-    unsigned long long lite_paths = 0;  // paths of the lite kernel's dispatches since the counters were reset
+    unsigned long long lite_paths = 0;  // paths since the counters were reset whose camera ray was not traced against the
+                                        // whole sphere list: the lite kernel's, the stream kernel's with cam_hits
     float4* d_split = nullptr;   // lights of the tiles whose frames several waves share (use_frame_split)
     size_t split_bytes = 0;
     unsigned order_tiles = 0;    // tiles d_tile_order orders (0: nothing yet), for the same region
     int order_uses = 0;          // dispatches that have used d_tile_order since it was sorted
+    unsigned order_serial = 0;   // sorts so far
+    uint4* d_units = nullptr;    // stream kernel: units of work made of d_tile_order (use_stream_split)
+    size_t units_cap = 0;
+    unsigned units_key[5] = {0}; // tiles, runs per heavy tile, frames per run, frames and order_serial d_units was made for
     int cost_region[4] = {0, 0, 0, 0};  // tile_col0, tile_cols, tile_row0, tile_rows of that dispatch
     float4* d_boxes = nullptr;    // per-lane traversal: boxes of the groups, then of the blocks (3 float4 per pair)
     int* d_perm = nullptr;        // sorted slot -> index in d_spheres
@@ -111,6 +116,8 @@ struct rt_context {
 
     int last_blocks = 0, last_threads = 0; // geometry of the last stream-kernel launch
     int last_mode = -1;                    // and its sieve: the values of rt_get_sieve_mode
+    int last_split[3] = {0, 0, 0};         // and how it shared heavy tiles: RtParams::split_ways, split_frames, split_tiles
+    const uint32_t* last_split_count = nullptr;  // ... and the device word with the tiles it split
     unsigned* d_work = nullptr;           // RT_WORK_BYTES: span counters + finished-workgroup count
     unsigned long long* d_rays = nullptr; // RT_RAY_BYTES: ray counters, summed by rt_get_counters
     uint64_t paths = 0;
@@ -668,7 +675,8 @@ int env_int(const char* name, int fallback) { return rt_dev_knob(name, fallback)
 // costs pixel by pixel instead of storing them tile by tile, so they are zeroed first, and
 // recorded only by the dispatch before a sort (an atomic per pixel is not free); stored costs are
 // recorded every time.  Does nothing (image order) when the arrays cannot be allocated.
-void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, int uses = 8)
+void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, int uses = 8, unsigned nwaves = 0,
+                    unsigned heavy_den = 1)
 {
     static const int uses_env = env_int("RT_DEBUG_LPT_USES", 0);  // development knob
     if (uses_env > 0) uses = uses_env;
@@ -682,7 +690,7 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
         c->d_tile_cost = c->d_tile_order = nullptr;
         c->tile_cap = c->cost_tiles = c->order_tiles = 0;
         if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 4) == hipSuccess &&
-            hipMalloc(&c->d_tile_order, (size_t)ntiles * 4) == hipSuccess) {
+            hipMalloc(&c->d_tile_order, ((size_t)ntiles + 2) * 4) == hipSuccess) {  // (+ the numbers of heavy tiles and of units)
             c->tile_cap = ntiles;
         } else {
             if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
@@ -698,9 +706,10 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
             c->order_uses++;
             P.tile_order = c->d_tile_order;
         } else if (c->cost_tiles == ntiles &&
-                   rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, c->stream) == hipSuccess) {
+                   rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, nwaves, heavy_den, c->stream) == hipSuccess) {
             c->order_tiles = ntiles;
             c->order_uses = 1;
+            c->order_serial++;
             P.tile_order = c->d_tile_order;
         } else {
             c->order_tiles = 0;
@@ -723,6 +732,7 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
 int use_camera_hits(rt_context* c, RtParams& P, bool fused)
 {
     P.cam_hits = nullptr;
+    P.cam_live = nullptr;
     if (!c->camera_shortcuts) return RT_OK;
     const unsigned ntiles = P.total_pixels / 64u;
     if (ntiles > c->hits_cap) {
@@ -730,7 +740,8 @@ int use_camera_hits(rt_context* c, RtParams& P, bool fused)
         c->d_cam_hits = nullptr;
         c->hits_cap = 0;
         c->hits_valid = false;
-        if (hipMalloc(&c->d_cam_hits, (size_t)ntiles * 64u * sizeof(uint2)) != hipSuccess) {
+        // (the hits of the pixels, then a word per tile: the pixels that hit a sphere)
+        if (hipMalloc(&c->d_cam_hits, (size_t)ntiles * (64u * sizeof(uint2) + sizeof(unsigned long long))) != hipSuccess) {
             (void)hipGetLastError();
             return RT_OK;
         }
@@ -742,12 +753,14 @@ int use_camera_hits(rt_context* c, RtParams& P, bool fused)
     memcpy(key + 12, ints, sizeof ints);
     if (!c->hits_valid || memcmp(key, c->hits_key, sizeof key) != 0) {
         c->hits_valid = false;
-        const hipError_t e = rt_launch_camera_hits(P, fused, c->d_cam_hits, c->stream);
+        const hipError_t e = rt_launch_camera_hits(P, fused, c->d_cam_hits,
+                                                   reinterpret_cast<unsigned long long*>(c->d_cam_hits + (size_t)c->hits_cap * 64u), c->stream);
         if (e != hipSuccess) return fail(RT_E_HIP, "camera hit kernel launch: %s", hipGetErrorString(e));
         memcpy(c->hits_key, key, sizeof key);
         c->hits_valid = true;
     }
     P.cam_hits = c->d_cam_hits;
+    P.cam_live = reinterpret_cast<const unsigned long long*>(c->d_cam_hits + (size_t)c->hits_cap * 64u);
     return RT_OK;
 }
 
@@ -769,6 +782,8 @@ void use_frame_split(rt_context* c, RtParams& P)
     P.split_frames = 0;
     P.split_lds = 0;
     P.split_lights = nullptr;
+    P.split_count = nullptr;
+    P.split_units = nullptr;
     if (share <= 0 || P.tile_order == nullptr || P.n_frames < 16) return;
     const unsigned ntiles = P.total_pixels / 64u;
     const unsigned slots = 20u * (unsigned)c->cu_count;  // waves of this kernel that the chip holds at a time
@@ -815,6 +830,67 @@ void use_frame_split(rt_context* c, RtParams& P)
     P.split_lights = c->d_split;
 }
 
+// Stream kernel, several frames per dispatch: the tiles that rt_tile_order_kernel counted as heavy (the first
+// order[ntiles] of the order, at most an eighth of the tiles) are traced as `ways` units of work each, a run of
+// frames per unit, and joined in frame order afterwards (rt_lite_join_kernel).  The units are listed on the device
+// (rt_tile_units_kernel), once per order and shape of dispatch; the lights of the later runs wait in device memory,
+// 1 KiB per tile and frame.  Does nothing without an order or when the buffers cannot be allocated.
+void use_stream_split(rt_context* c, RtParams& P, int ways_max)
+{
+    P.split_tiles = 0;
+    P.split_ways = 0;
+    P.split_frames = 0;
+    P.split_lds = 0;
+    P.split_lights = nullptr;
+    P.split_count = nullptr;
+    P.split_units = nullptr;
+    if (ways_max < 2 || P.tile_order == nullptr || P.n_frames < 2) return;
+    const unsigned ntiles = P.total_pixels / 64u;
+    const int frames = (P.n_frames + std::min(ways_max, P.n_frames) - 1) / std::min(ways_max, P.n_frames);
+    const int ways = (P.n_frames + frames - 1) / frames;  // every run holds a frame
+    if (ways < 2) return;
+    const size_t per_tile = (size_t)ways * (size_t)frames * 64u * sizeof(float4);
+    const size_t tiles = std::min<size_t>(ntiles / 8u, ((size_t)1 << 29) / per_tile);
+    if (tiles == 0) return;
+    if (tiles * per_tile > c->split_bytes) {
+        if (c->d_split) (void)hipFree(c->d_split);
+        c->d_split = nullptr;
+        c->split_bytes = 0;
+        if (hipMalloc(&c->d_split, tiles * per_tile) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        c->split_bytes = tiles * per_tile;
+    }
+    const size_t n_units = (size_t)ntiles + tiles * (size_t)(ways - 1);
+    if (n_units > c->units_cap) {
+        if (c->d_units) (void)hipFree(c->d_units);
+        c->d_units = nullptr;
+        c->units_cap = 0;
+        if (hipMalloc(&c->d_units, n_units * sizeof(uint4)) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        c->units_cap = n_units;
+        c->units_key[0] = 0;
+    }
+    const unsigned key[5] = {ntiles, (unsigned)ways, (unsigned)frames, (unsigned)P.n_frames, c->order_serial};
+    if (memcmp(key, c->units_key, sizeof key) != 0) {
+        c->units_key[0] = 0;
+        if (rt_launch_tile_units(c->d_tile_order, c->d_units, ntiles, (unsigned)tiles, ways, frames, P.n_frames, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        memcpy(c->units_key, key, sizeof key);
+    }
+    P.split_tiles = (int)tiles;
+    P.split_ways = ways;
+    P.split_frames = frames;
+    P.split_count = c->d_tile_order + ntiles;
+    P.split_units = c->d_units;
+    P.split_lights = c->d_split;
+}
+
 int launch(rt_context* c, const RtParams& P_in, bool record)
 {
     RtParams P = P_in;
@@ -853,11 +929,15 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         if (c->camera_shortcuts)  // every camera ray is traced against its tile's candidates
             c->lite_paths += (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
         c->last_mode = 4;
+        c->last_split[0] = c->last_split[1] = c->last_split[2] = 0;
+        c->last_split_count = nullptr;
         return RT_OK;
     }
     if (tile) {
         HIP_TRY(rt_launch_tile(P, fused, record, c->stream));
         c->last_mode = -1;
+        c->last_split[0] = c->last_split[1] = c->last_split[2] = 0;
+        c->last_split_count = nullptr;
         return RT_OK;
     }
     const bool mfma = wants_mfma(c, P);
@@ -875,6 +955,8 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     }
     if (rt_stream_lds_bytes(P.n_lds, threads, mfma && !far, 0, P.sg_wide) > kLdsPerCu)
         return fail(RT_E_INVALID, "workgroup of %d threads needs more than 160 KiB of LDS", threads);
+    if (P.width > 0xffff || P.height > 0xffff)  // a lane holds its pixel as x | y << 16
+        return fail(RT_E_INVALID, "image of %d x %d pixels is too large for the stream kernel", P.width, P.height);
     if ((unsigned long long)P.tile_cols * P.tile_cols * P.tile_rows >= 0x100000000ull)
         return fail(RT_E_INVALID, "image of %d x %d tiles is too large for the stream kernel", P.tile_cols,
                     P.tile_rows);
@@ -910,8 +992,21 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     // (16 384 spheres 4.35 -> 4.75 ms: its dispatch is short and its tail is not what bounds it).
     static const int lpt_min_spheres = env_int("RT_DEBUG_LPT_STREAM_SPHERES", 0);  // development knob; < 0: never
     if (!record && mode != 6 && lpt_min_spheres >= 0 && P.sphere_count >= lpt_min_spheres &&
-        (long long)P.total_pixels * P.n_frames >= (1 << 22))
-        use_tile_order(c, P, true, true);
+        (long long)P.total_pixels * P.n_frames >= (1 << 22)) {
+        // Several frames of an image of few tiles per wave: the heavy tiles in runs of frames (use_stream_split).  A tile is
+        // heavy from 1 / split_den of the passes an average wave of the dispatch makes.  Measured on the 484-sphere scene,
+        // 8 frames, without / with: 1920x1080 (10 tiles per wave) 2.31 -> 1.90 ms, 2560x1440 (19) 3.03 -> 2.90 ms,
+        // 3840x2160 (42) 5.47 -> 5.60 ms (nothing left to gain at the end of the dispatch, and the instantiation that
+        // can park lights is 2 % slower); 4096 spheres at 3840x2160 x 2 frames 7.55 -> 7.45 ms.
+        static const int split_den = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_DEN", 8);      // 0 = never
+        static const int split_ways = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_WAYS", 4);
+        static const int split_tiles = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_TILES", 24);  // tiles per wave up to which
+        const unsigned nwaves = (unsigned)blocks * (unsigned)threads / 64u;
+        const bool split = split_den > 0 && (mode == 0 || mode == 1 || mode == 3 || mode == 5) &&
+                           P.total_pixels / 64u <= (unsigned)split_tiles * nwaves;
+        use_tile_order(c, P, true, true, 8, split ? nwaves : 0u, (unsigned)std::max(1, split_den));
+        if (split) use_stream_split(c, P, split_ways);
+    }
     P.cam_reuse = !record && c->camera_shortcuts;
     if (!record) {
         const int rc = use_camera_hits(c, P, fused);
@@ -933,14 +1028,23 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
         (void)hipMemsetAsync(c->d_work, 0xff, RT_WORK_BYTES, c->stream);
         e = hipErrorLaunchFailure;
     } else {
-        e = rt_launch_stream(P, fused, record, mode, blocks, threads, c->stream);
+        // the pixels that see the sky, all their frames; the stream kernel has the others (disjoint: any order)
+        if (P.cam_live != nullptr) e = rt_launch_sky_frames(P, fused, c->stream);
+        if (e == hipSuccess) e = rt_launch_stream(P, fused, record, mode, blocks, threads, c->stream);
+        if (e == hipSuccess && P.split_count != nullptr) e = rt_launch_stream_join(P, c->stream);
     }
     if (e != hipSuccess) {
         reset_work(c);
         return fail(RT_E_HIP, "stream kernel launch (%d x %d): %s", blocks, threads, hipGetErrorString(e));
     }
+    if (P.cam_hits != nullptr)  // every camera ray's hit was looked up
+        c->lite_paths += (unsigned long long)P.total_pixels * (unsigned)P.n_frames;
     c->last_blocks = blocks;
     c->last_threads = threads;
+    c->last_split[0] = P.split_count ? P.split_ways : 0;
+    c->last_split[1] = P.split_count ? P.split_frames : 0;
+    c->last_split[2] = P.split_count ? P.split_tiles : 0;
+    c->last_split_count = P.split_count;
     c->last_mode = mode == 4 || mode == 6 ? 6 : mode == 5 ? 3 : mode;
     return RT_OK;
 }
@@ -1017,6 +1121,7 @@ int rt_destroy(rt_context* c)
     if (c->d_boxes) (void)hipFree(c->d_boxes);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+    if (c->d_units) (void)hipFree(c->d_units);
     if (c->d_split) (void)hipFree(c->d_split);
     if (c->d_cam_hits) (void)hipFree(c->d_cam_hits);
     if (c->d_perm) (void)hipFree(c->d_perm);
@@ -1240,6 +1345,23 @@ int rt_get_info(rt_context* c, int* device, int* cu_count, int* blocks, int* thr
     if (b == 0 && c->have_ubo && make_params(c, 1, &P) == RT_OK) stream_geometry(c, P, &b, &t);
     if (blocks) *blocks = b;
     if (threads) *threads = t;
+    return RT_OK;
+}
+
+int rt_debug_split_info(rt_context* c, int out[4])
+{
+    if (!c || !out) return fail(RT_E_INVALID, "null argument");
+    RT_ON_DEVICE(c);
+    out[0] = c->last_split[0];
+    out[1] = c->last_split[1];
+    out[2] = c->last_split[2];
+    out[3] = 0;
+    if (c->last_split_count != nullptr) {
+        uint32_t heavy = 0;
+        HIP_TRY(hipMemcpyAsync(&heavy, c->last_split_count, sizeof heavy, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        out[3] = (int)std::min<uint32_t>(heavy, (uint32_t)c->last_split[2]);
+    }
     return RT_OK;
 }
 
@@ -1608,7 +1730,7 @@ int rt_get_counters(rt_context* c, rt_counters* out)
 #ifndef RT_PHASE_TIMERS
     for (unsigned i = 0; i < RT_RAY_SLOTS; i++) list_rays += slots[i * RT_RAY_SLOT_STRIDE + 4];
 #endif
-    list_rays += c->lite_paths;  // the lite kernel: every camera ray, and an atomic per wave would cost it 6 %
+    list_rays += c->lite_paths;  // every camera ray of those dispatches (an atomic per wave would cost the lite kernel 6 %)
     out->rays = rays;
     out->sphere_tests = tests;
     out->paths = c->paths;

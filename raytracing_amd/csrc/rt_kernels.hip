@@ -995,19 +995,27 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
 __global__ void __launch_bounds__(256) rt_lite_join_kernel(const RtParams P)
 {
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (slot >= (uint32_t)P.split_tiles) return;
+    // (stream kernel: the number of split tiles is the order kernel's, at most split_tiles)
+    const uint32_t count = P.split_count != nullptr ? min(*P.split_count, (uint32_t)P.split_tiles) : (uint32_t)P.split_tiles;
+    if (slot >= count) return;
     const uint32_t tile = P.tile_order[slot];
     const uint32_t lane = threadIdx.x & 63u;
+    if (P.cam_live != nullptr && ((P.cam_live[tile] >> lane) & 1ull) == 0ull) return;  // a sky pixel: no run has traced it
     const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
     const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
     const uint32_t px = ((uint32_t)P.tile_col0 + tx) * 8 + (lane & 7u);
     const uint32_t py = ((uint32_t)P.tile_row0 + ty) * 8 + (lane >> 3);
     float4 acc = P.accum[(size_t)py * P.width + px];
-    const float4* lights = P.split_lights + (size_t)slot * (size_t)(P.split_ways - 1) * (size_t)P.split_frames * 64u + lane;
+    // lite kernel: run r, frame k of it at (r - 1) * split_frames + k of the tile's lights; stream kernel: frame j at j
+    // (the first split_frames places stay empty)
+    const float4* lights = P.split_lights + lane +
+                           (P.split_count != nullptr
+                                ? (ptrdiff_t)slot * P.split_ways * (ptrdiff_t)P.split_frames * 64
+                                : ((ptrdiff_t)slot * (P.split_ways - 1) - 1) * (ptrdiff_t)P.split_frames * 64);
     for (int j = P.split_frames; j < P.n_frames; j++) {
         const uint32_t frame = P.frame0 + (uint32_t)(j * P.frame_stride);
         if (clear_at(P, j, frame)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 l = lights[(size_t)(j - P.split_frames) * 64u];  // run r, frame k of it: (r - 1) * split_frames + k
+        const float4 l = lights[(size_t)j * 64u];
         acc.x = l.x + acc.x;  // vec4(light, 1.0) + accumulated
         acc.y = l.y + acc.y;
         acc.z = l.z + acc.z;
@@ -1023,16 +1031,31 @@ __global__ void __launch_bounds__(256) rt_lite_join_kernel(const RtParams P)
 // waiting for them (measured: 25 % of the vector ALU idle at 1080p x 64 frames).  Longest first,
 // they start at once and the light ones fill in behind.  The order only says who goes first: the
 // bits of the image cannot depend on it.  One workgroup of 1024 threads; n = number of tiles.
-__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cost, uint32_t* order, unsigned n)
+// order[n] = the number of leading tiles of the order that are HEAVY: whose rays, traced 64 at a time by one wave,
+// are more passes than 1 / heavy_den of what an average wave of `nwaves` traces in the whole dispatch (0 with
+// nwaves == 0).  The stream kernel shares the frames of those tiles among several waves (RtParams::split_*).
+__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cost, uint32_t* order, unsigned n,
+                                                             unsigned nwaves, unsigned heavy_den)
 {
     __shared__ unsigned s_max;
     __shared__ unsigned s_bin[256];
+    __shared__ unsigned long long s_sum;
+    __shared__ unsigned s_heavy;
+    if (threadIdx.x == 0) {
+        s_sum = 0ull;
+        s_heavy = 0u;
+    }
     if (threadIdx.x == 0) s_max = 1u;
     if (threadIdx.x < 256) s_bin[threadIdx.x] = 0u;
     __syncthreads();
     unsigned m = 0;
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) m = max(m, cost[i]);
+    unsigned long long sum = 0ull;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        m = max(m, cost[i]);
+        sum += cost[i];
+    }
     atomicMax(&s_max, m);
+    if (nwaves != 0u) atomicAdd(&s_sum, sum);
     __syncthreads();
     const float scale = 255.0f / (float)s_max;
     auto cls = [&](unsigned c) { return 255u - min(255u, (unsigned)((float)c * scale)); };  // class 0 = heaviest
@@ -1047,7 +1070,48 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
         }
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&s_bin[cls(cost[i])], 1u)] = i;
+    // heavy: cost / 64 passes >= (sum / 64 / nwaves) / heavy_den
+    const unsigned long long heavy_from = nwaves != 0u ? s_sum / ((unsigned long long)nwaves * heavy_den) + 1ull : ~0ull;
+    unsigned heavy = 0;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        order[atomicAdd(&s_bin[cls(cost[i])], 1u)] = i;
+        heavy += cost[i] >= heavy_from ? 1u : 0u;
+    }
+    if (heavy != 0u) atomicAdd(&s_heavy, heavy);
+    __syncthreads();
+    if (threadIdx.x == 0) order[n] = s_heavy;
+}
+
+// Lane state `park` of the instantiations that share the frames of heavy tiles among several units of work: where the
+// lights of the lane's run of frames go.  A pixel of a tile that is not split: RT_PARK_NONE (all frames in this lane,
+// the texel stored at the end); the first run of a split tile: RT_PARK_FIRST (its sum goes to the accumulation image
+// and rt_lite_join_kernel adds the other runs); a later run: RT_PARK_LATER + 4 x the index in RtParams::split_lights
+// of the light of the pixel's frame 0, the light of frame j 64 j further on.
+#define RT_PARK_LATER 0u
+#define RT_PARK_FIRST 1u
+#define RT_PARK_NONE 2u
+
+// The units of work of a dispatch of the stream kernel that shares the frames of heavy tiles, in the order they are
+// handed out: `ways` runs of `frames` frames for each of the first S tiles of the order (S = order[n], the heavy tiles
+// rt_tile_order_kernel counted, at most `cap`), then the other tiles with all their frames.  units[u] = {tile, first
+// frame, end frame, RT_PARK_*: for a run after a tile's first, 4 x the index in the parked lights of the light of
+// lane 0's frame 0}; order[n + 1] = the number of units.  One thread per unit, n + cap * (ways - 1) at least.
+__global__ void __launch_bounds__(256) rt_tile_units_kernel(uint32_t* order, uint4* units, unsigned n, unsigned cap, unsigned ways,
+                                                            unsigned frames, unsigned n_frames)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t heavy = min(order[n], cap);
+    const uint32_t n_units = n + heavy * (ways - 1u);
+    if (u == 0u) order[n + 1] = n_units;
+    if (u >= n_units) return;
+    if (u < heavy * ways) {
+        const uint32_t slot = u / ways, run = u - slot * ways;
+        const uint32_t j0 = run * frames;
+        units[u] = make_uint4(order[slot], j0, min(n_frames, j0 + frames),
+                              run == 0u ? RT_PARK_FIRST : RT_PARK_LATER + ((slot * ways * frames * 64u) << 2));
+    } else {
+        units[u] = make_uint4(order[u - heavy * (ways - 1u)], 0u, n_frames, RT_PARK_NONE);
+    }
 }
 
 // Nearest hit of the camera ray of every pixel, for rt_stream_kernel.  The camera ray of a pixel is the
@@ -1057,9 +1121,9 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
 // rt_lite_kernel (tile_cone_keeps) over the whole sphere list, 64 spheres at a time with a sphere per
 // lane, leaves the few spheres that any camera ray of the tile can meet; every lane then evaluates the
 // shader's own test (test_sphere) on those, in index order.  hits[tile * 64 + lane] = {sphere index or
-// -1, bits of t}.  blockDim.x = a multiple of 64.
+// -1, bits of t}; live[tile] = the lanes whose camera ray hits a sphere.  blockDim.x = a multiple of 64.
 template <bool FUSED>
-__global__ void __launch_bounds__(256) rt_camera_hits_kernel(const RtParams P, uint2* hits)
+__global__ void __launch_bounds__(256) rt_camera_hits_kernel(const RtParams P, uint2* hits, unsigned long long* live)
 {
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile >= (uint32_t)P.tile_cols * (uint32_t)P.tile_rows) return;  // wave-uniform
@@ -1103,6 +1167,45 @@ __global__ void __launch_bounds__(256) rt_camera_hits_kernel(const RtParams P, u
         }
     }
     hits[(size_t)tile * 64u + lane] = make_uint2((uint32_t)idx, __float_as_uint(best));
+    const unsigned long long mask = __ballot(idx >= 0);
+    if (lane == 0) live[tile] = mask;
+}
+
+// The pixels whose camera ray goes to the sky (P.cam_hits says which), all frames of the dispatch: every frame is
+// one Trace() call and light = sky_color * (0.15, 0.15, 0.15) (shader.comp:94-102), added frame by frame in the
+// shader's order with the clears where they fall.  rt_stream_kernel takes only the other pixels (P.cam_live).
+// A wave per tile at a time, tiles strided over the grid; blockDim.x = a multiple of 64.
+template <bool FUSED>
+__global__ void __launch_bounds__(256) rt_sky_frames_kernel(const RtParams P)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_tiles = (uint32_t)P.tile_cols * (uint32_t)P.tile_rows;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    unsigned nrays = 0;
+    for (uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += waves) {
+        if ((P.cam_live[tile] >> lane) & 1ull) continue;
+        const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
+        const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
+        const uint32_t px = ((uint32_t)P.tile_col0 + tx) * 8 + (lane & 7u);
+        const uint32_t py = ((uint32_t)P.tile_row0 + ty) * 8 + (lane >> 3);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!clear_at(P, 0, P.frame0)) acc = P.accum[(size_t)py * P.width + px];
+        float dx, dy, dz;
+        primary_direction<FUSED>(P, px, py, dx, dy, dz);
+        Path p;
+        path_reset(p, P, dx, dy, dz);
+        (void)path_bounce<FUSED, false>(p, P, -1, RT_FLT_MAX, px, py, 0u, nullptr, nullptr);
+        for (int j = 0; j < P.n_frames; j++) {
+            if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x = p.lr + acc.x;  // vec4(light, 1.0) + accumulated
+            acc.y = p.lg + acc.y;
+            acc.z = p.lb + acc.z;
+            acc.w = 1.0f + acc.w;
+        }
+        nrays += (unsigned)P.n_frames;
+        store_pixel(P, px, py, acc);
+    }
+    add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 
 // ------------------------------------------------- sieve on the matrix cores
@@ -1817,17 +1920,34 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 // kernel a private segment and a third of its scalar registers in spills.
 #define RT_STREAM_SHADE(best_, idx_)                                                                                        \
     {                                                                                                                       \
+        const uint32_t px = pxy & 0xffffu, py = pxy >> 16;                                                                  \
         nrays++;                                                                                                            \
         if (path_bounce<FUSED, RECORD>(p, P, idx_, best_, px, py, P.frame0 + (uint32_t)(j * P.frame_stride), rec, table)) { \
             if constexpr (RECORD) record_light(P, px, py, j, p);                                                            \
-            acc.x = p.lr + acc.x; /* vec4(light, 1.0) + accumulated */                                                      \
-            acc.y = p.lg + acc.y;                                                                                           \
-            acc.z = p.lb + acc.z;                                                                                           \
-            acc.w = 1.0f + acc.w;                                                                                           \
-            j++;                                                                                                            \
-            if (j == P.n_frames) {                                                                                          \
+            /* the end of the lane's frames: the last frame, or the last of its run of a split tile */                      \
+            const int jn = j + 1;                                                                                           \
+            const bool last = jn == (SPLIT ? jend : P.n_frames);                                                            \
+            if (SPLIT && (park & 3u) == RT_PARK_LATER) { /* a run after a split tile's first: the light waits for the join */ \
+                P.split_lights[(park >> 2) + (uint32_t)j * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);                       \
+            } else {                                                                                                        \
+                /* (the frame's clear, if one falls on it: nothing has touched the texel since the frame began) */          \
+                if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f); \
+                acc.x = p.lr + acc.x; /* vec4(light, 1.0) + accumulated */                                                  \
+                acc.y = p.lg + acc.y;                                                                                       \
+                acc.z = p.lb + acc.z;                                                                                       \
+                acc.w = 1.0f + acc.w;                                                                                       \
                 if constexpr (!RECORD) {                                                                                    \
-                    store_pixel(P, px, py, acc);                                                                            \
+                    if (last) {                                                                                             \
+                        if (!SPLIT || park == RT_PARK_NONE)                                                                 \
+                            store_pixel(P, px, py, acc);                                                                    \
+                        else /* a split tile's first run: the join adds the rest */                                         \
+                            P.accum[(size_t)py * P.width + px] = acc;                                                       \
+                    }                                                                                                       \
+                }                                                                                                           \
+            }                                                                                                               \
+            j = jn;                                                                                                         \
+            if (last) {                                                                                                     \
+                if constexpr (!RECORD) {                                                                                    \
                     if (P.tile_cost != nullptr) /* the pixel's rays go to its tile's cost, for the next dispatch's order */ \
                         atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +               \
                                       ((px >> 3) - (uint32_t)P.tile_col0),                                                  \
@@ -1845,10 +1965,16 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 // the shader's order with the clears where they fall.  The pixel is stored and its lane is free.
 #define RT_STREAM_SKY_FRAMES                                                                                        \
     {                                                                                                               \
+        const uint32_t px = pxy & 0xffffu, py = pxy >> 16;                                                          \
         path_reset(p, P, d0x, d0y, d0z);                                                                            \
         (void)path_bounce<FUSED, false>(p, P, -1, RT_FLT_MAX, px, py, 0u, nullptr, nullptr);                        \
-        const unsigned left = (unsigned)(P.n_frames - j);                                                           \
-        for (; j < P.n_frames; j++) {                                                                               \
+        const int jstop = SPLIT ? jend : P.n_frames;                                                                \
+        const unsigned left = (unsigned)(jstop - j);                                                                \
+        for (; j < jstop; j++) {                                                                                    \
+            if (SPLIT && (park & 3u) == RT_PARK_LATER) {                                                            \
+                P.split_lights[(park >> 2) + (uint32_t)j * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);               \
+                continue;                                                                                           \
+            }                                                                                                       \
             if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f); \
             acc.x = p.lr + acc.x;                                                                                   \
             acc.y = p.lg + acc.y;                                                                                   \
@@ -1856,8 +1982,8 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
             acc.w = 1.0f + acc.w;                                                                                   \
         }                                                                                                           \
         nrays += left;                                                                                              \
-        nlist += left;                                                                                              \
-        store_pixel(P, px, py, acc);                                                                                \
+        if (!SPLIT || park == RT_PARK_NONE) store_pixel(P, px, py, acc);                                            \
+        if (SPLIT && park == RT_PARK_FIRST) P.accum[(size_t)py * P.width + px] = acc;                               \
         if (P.tile_cost != nullptr)                                                                                 \
             atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +                   \
                           ((px >> 3) - (uint32_t)P.tile_col0),                                                      \
@@ -1867,14 +1993,35 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
     }
 
 #define RT_CAM_UNKNOWN (-2)
+// COLD instantiations keep what only the shading of a ray needs in LDS while the ray is traced, not in registers:
+// ten words per lane, cold_w[k * RT_MFMA_MAX_THREADS + thread] (fixed strides: the offsets go into the instructions).
+#define RT_COLD_CR 0  // what the path has gathered (Path::cr .. lb)
+#define RT_COLD_CG 1
+#define RT_COLD_CB 2
+#define RT_COLD_LR 3
+#define RT_COLD_LG 4
+#define RT_COLD_LB 5
+#define RT_COLD_BOUNCE 6
+#define RT_COLD_J 7
+#define RT_COLD_PXY 8
+#define RT_COLD_NRAYS 9
+#define RT_COLD_WORDS 10
+#ifndef RT_COLD_N
+#define RT_COLD_N 10
+#endif
 
-template <bool FUSED, bool RECORD, int MODE>
-__global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
+// MODE_ = the sieve (MODE below), + RT_STREAM_SPLIT for the instantiation that shares the frames of heavy tiles.
+#define RT_STREAM_SPLIT 16
+template <bool FUSED, bool RECORD, int MODE_>
+__global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
 {
+    constexpr int MODE = MODE_ & 15;
+    constexpr bool SPLIT = (MODE_ & RT_STREAM_SPLIT) != 0 && !RECORD;
     constexpr bool SGEOM = MODE == 1 || MODE == 2;
     constexpr bool CULL = MODE == 2;
     constexpr bool MFMA = MODE == 3 || MODE == 5 || MODE == 7;
     constexpr bool PIPE = MODE != 7;  // 7 = 3 for workgroups of more than RT_STREAM_MAX_THREADS threads (three waves per SIMD)
+    constexpr bool COLD = MODE == 7 && RT_COLD_N > 0;  // ... which has no register to spare over the sieve
     constexpr bool FAR_FRAGS = MODE == 5;  // matrix-core sieve with its sphere-side operands left in global memory
     constexpr bool BVH = MODE == 4;
     constexpr bool BVH_FAR = MODE == 6;  // per-lane traversal out of global memory (nothing staged: P.n_lds == 0)
@@ -1905,15 +2052,26 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
     uint32_t* wmask = reinterpret_cast<uint32_t*>(lds_table + 2 * P.n_table) + wave * (sg_chunks * 64);
     const float* gf = reinterpret_cast<const float*>(smem);
     const int nch = P.n_pad / RT_CHUNK;
+    uint32_t* cold_w = reinterpret_cast<uint32_t*>(lds_table + 2 * P.n_table) + (blockDim.x >> 6) * (sg_chunks * 64);
+    (void)cold_w;
 
     // wave-uniform work span.  Spans of RT_SPAN pixels are dealt round-robin into RT_QUEUES
     // queues, each with a counter on a cache line of its own: atomics on one address complete one
     // at a time (~10 ns each).  A wave draws from the queue of its workgroup (workgroups go
     // round-robin over the XCDs, so that is one queue per XCD) and moves on to another queue when
     // its own runs dry.
-    const uint32_t nspans = (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
+    // SPLIT: heavy tiles (rt_tile_order_kernel counts them) are several units of work each, a run of frames per unit: a
+    // tile in the crevice between two spheres bounces to the depth limit in every pixel and frame, and all its frames
+    // in one lane are a chain of frames x depth passes that nothing shortens but sharing the frames.  The units are
+    // listed in P.split_units (rt_tile_units_kernel), the runs of the heavy tiles first.
+    const uint32_t nspans = SPLIT ? P.split_count[1] : (P.total_pixels + RT_SPAN - 1) / RT_SPAN;
     uint32_t queue = blockIdx.x % RT_QUEUES;
-    uint32_t span_cur = 0, span_end = 0;
+    // the wave's unit of work: the pixels of its tile not yet handed to a lane, the tile, SPLIT: its run of frames
+    unsigned long long avail = 0ull;
+    uint32_t span_tile = 0;
+    int span_j0 = 0, span_jend = 0;
+    uint32_t span_park = RT_PARK_NONE;
+    (void)span_j0; (void)span_jend; (void)span_park;
     bool exhausted = false;
     auto queue_len = [&](uint32_t q) -> uint32_t { return (nspans + RT_QUEUES - 1 - q) / RT_QUEUES; };
     // Lane 0 asks a queue for its next span; the answer is left in a vector register so that
@@ -1945,10 +2103,12 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
 
     // lane state
     bool alive = false, start = false;
-    uint32_t px = 0, py = 0;
+    uint32_t pxy = 0;  // the lane's pixel: x | y << 16
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned nrays = 0, nlist = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
+    unsigned nrays = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
+    int jend = 0;                   // SPLIT: the lane's frames end here
+    uint32_t park = RT_PARK_NONE;   // SPLIT: see RT_PARK_NONE
 #ifdef RT_COUNT_PASSES
     unsigned npasses = 0;  // experiment: passes over the sphere list, added to the word after the ray counter
     unsigned npasslanes = 0;  // and the lanes that held a ray in them (word 3)
@@ -1984,7 +2144,7 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         // ---- refill: free lanes take the next pixels of the wave's span
         unsigned long long freem = __ballot(!alive);
         while (freem != 0ull && !exhausted) {
-            if (span_cur == span_end) {
+            if (avail == 0ull) {
                 // spans q, q + RT_QUEUES, ... belong to queue q
                 const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
                 have_ahead = false;
@@ -1996,53 +2156,71 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
                     }
                     continue;
                 }
-                span_cur = (k * RT_QUEUES + queue) * RT_SPAN;
-                span_end = min(span_cur + RT_SPAN, P.total_pixels);
                 if (prefetch) {
                     // short spans: ask for the next one now and read the answer when this one is used up
                     ahead = ask(queue);
                     have_ahead = true;
                 }
+                const uint32_t slot = k * RT_QUEUES + queue;  // (a span is the 64 pixels of a tile)
+                if constexpr (SPLIT) {  // the unit: a tile and a run of its frames
+                    const uint4 unit = P.split_units[slot];
+                    span_tile = __builtin_amdgcn_readfirstlane(unit.x);
+                    span_j0 = (int)__builtin_amdgcn_readfirstlane(unit.y);
+                    span_jend = (int)__builtin_amdgcn_readfirstlane(unit.z);
+                    span_park = __builtin_amdgcn_readfirstlane(unit.w);
+                } else {  // heaviest tiles of the previous dispatch first when their costs are known
+                    span_tile = P.tile_order != nullptr ? __builtin_amdgcn_readfirstlane(P.tile_order[slot]) : slot;
+                }
+                // the pixels whose camera ray meets a sphere, when that is known: rt_sky_frames_kernel has the others
+                avail = ~0ull;
+                if constexpr (!RECORD) {
+                    if (P.cam_live != nullptr) {
+                        const unsigned long long live = P.cam_live[span_tile];
+                        avail = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(live >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)live);
+                    }
+                }
+                if (avail == 0ull) continue;
             }
-            const uint32_t navail = span_end - span_cur;
+            // free lane number r takes the r-th pixel left: lane p, where the r-th set bit of avail is, sends p to
+            // lane r, and the r-th free lane fetches it there
+            const uint32_t ntake = min((uint32_t)__popcll(freem), (uint32_t)__popcll(avail));
             const uint32_t rank = mbcnt64(freem);
-            const bool took = !alive && rank < navail;
-            uint32_t took_tile = 0, took_l = 0;
+            const bool took = !alive && rank < ntake;
+            const uint32_t arank = mbcnt64(avail);
+            const bool given = ((avail >> lane) & 1ull) != 0ull && arank < ntake;
+            const unsigned long long givenm = __ballot(given);
+            // (every lane sends, to a lane of its own: the others fill the places ntake .. 63)
+            const int nth = __builtin_amdgcn_ds_permute((int)((given ? arank : ntake + mbcnt64(~givenm)) << 2), lane);
+            const uint32_t l = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), nth);
+            avail &= ~givenm;
             if (took) {
-                const uint32_t pix = span_cur + rank;
-                const uint32_t l = pix & 63u;
-                // span -> tile: heaviest tiles of the previous dispatch first when their costs are known
-                const uint32_t tile = P.tile_order ? P.tile_order[pix >> 6] : pix >> 6;
-                took_tile = tile;
-                took_l = l;
+                const uint32_t tile = span_tile;
+                j = 0;
+                if constexpr (SPLIT) {
+                    j = span_j0;
+                    jend = span_jend;
+                    park = span_park + ((span_park & 3u) == RT_PARK_LATER ? l << 2 : 0u);
+                }
                 // tile / tile_cols by multiplication: exact for tile < 2^24 (checked on the host)
                 const uint32_t ty = P.tile_cols_magic ? __umulhi(tile, P.tile_cols_magic) : tile;
                 const uint32_t tx = tile - ty * (uint32_t)P.tile_cols;
-                px = ((uint32_t)P.tile_col0 + tx) * 8 + (l & 7u);
-                py = ((uint32_t)P.tile_row0 + ty) * 8 + (l >> 3);
+                const uint32_t px = ((uint32_t)P.tile_col0 + tx) * 8 + (l & 7u);
+                const uint32_t py = ((uint32_t)P.tile_row0 + ty) * 8 + (l >> 3);
+                pxy = px | py << 16;
                 primary_direction<FUSED>(P, px, py, d0x, d0y, d0z);
-                j = 0;
                 pixel_rays0 = nrays;
                 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (!RECORD)
-                    if (!clear_at(P, 0, P.frame0)) acc = P.accum[(size_t)py * P.width + px];
+                    if ((!SPLIT || (park & 3u) != RT_PARK_LATER) && !clear_at(P, 0, P.frame0)) acc = P.accum[(size_t)py * P.width + px];
                 alive = true;
                 start = true;
                 cam = RT_CAM_UNKNOWN;
-            }
-            span_cur += min((uint32_t)__popcll(freem), navail);
-
-            // ---- Trace() of the new pixels' camera rays: found once per camera and scene for every pixel
-            // (rt_camera_hits_kernel), the hit holds for every frame of the dispatch (cam, cam_t).  A pixel that
-            // sees the sky is finished here and now, all its frames, and its lane takes another pixel in the
-            // next round of this loop.
-            if constexpr (!RECORD) {
-                if (P.cam_hits != nullptr) {  // wave-uniform
-                    if (took) {
-                        const uint2 h = P.cam_hits[(size_t)took_tile * 64u + took_l];
+                if constexpr (!RECORD) {
+                    if (P.cam_hits != nullptr) {  // wave-uniform: the hit of the pixel's camera ray is known (never the sky)
+                        const uint2 h = P.cam_hits[(size_t)tile * 64u + l];
                         cam = (int)h.x;
                         cam_t = __uint_as_float(h.y);
-                        if (cam < 0) RT_STREAM_SKY_FRAMES
                     }
                 }
             }
@@ -2061,18 +2239,15 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         if constexpr (!RECORD) {
             while (__ballot(alive && start && cam >= 0) != 0ull) {
                 if (alive && start && cam >= 0) {
-                    if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     path_reset(p, P, d0x, d0y, d0z);
                     start = false;
-                    nlist++;
                     RT_STREAM_SHADE(cam_t, cam)
                 }
             }
         }
         // ---- the others generate their camera ray
         if (start) {
-            if (j > 0 && clear_at(P, j, P.frame0 + (uint32_t)(j * P.frame_stride))) acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (RECORD) rec = record_slot(P, px, py, j);
+            if constexpr (RECORD) rec = record_slot(P, pxy & 0xffffu, pxy >> 16, j);
             path_reset(p, P, d0x, d0y, d0z);
             start = false;
         }
@@ -2084,6 +2259,22 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         npasslanes += (unsigned)__popcll(__ballot(tracing));
 #endif
         // ---- Trace(): sieve + candidate walk
+        if constexpr (COLD) {  // what the path has gathered so far waits in LDS: the shading is the next to look at it
+            cold_w[RT_COLD_CR * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.cr);
+            cold_w[RT_COLD_CG * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.cg);
+            cold_w[RT_COLD_CB * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.cb);
+            cold_w[RT_COLD_LR * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.lr);
+            cold_w[RT_COLD_LG * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.lg);
+            cold_w[RT_COLD_LB * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.lb);
+            cold_w[RT_COLD_BOUNCE * RT_MFMA_MAX_THREADS + threadIdx.x] = (uint32_t)p.bounce;
+            cold_w[RT_COLD_J * RT_MFMA_MAX_THREADS + threadIdx.x] = (uint32_t)j;
+#if RT_COLD_N > 8
+            cold_w[RT_COLD_PXY * RT_MFMA_MAX_THREADS + threadIdx.x] = pxy;
+#endif
+#if RT_COLD_N > 9
+            cold_w[RT_COLD_NRAYS * RT_MFMA_MAX_THREADS + threadIdx.x] = nrays;
+#endif
+        }
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
         int idx = -1;
@@ -2238,6 +2429,22 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
             if (idx >= 0) idx = P.perm[idx];  // slot of the sorted list -> the shader's sphere index
 
         // ---- shade
+        if constexpr (COLD) {
+            p.cr = __uint_as_float(cold_w[RT_COLD_CR * RT_MFMA_MAX_THREADS + threadIdx.x]);
+            p.cg = __uint_as_float(cold_w[RT_COLD_CG * RT_MFMA_MAX_THREADS + threadIdx.x]);
+            p.cb = __uint_as_float(cold_w[RT_COLD_CB * RT_MFMA_MAX_THREADS + threadIdx.x]);
+            p.lr = __uint_as_float(cold_w[RT_COLD_LR * RT_MFMA_MAX_THREADS + threadIdx.x]);
+            p.lg = __uint_as_float(cold_w[RT_COLD_LG * RT_MFMA_MAX_THREADS + threadIdx.x]);
+            p.lb = __uint_as_float(cold_w[RT_COLD_LB * RT_MFMA_MAX_THREADS + threadIdx.x]);
+            p.bounce = (int)cold_w[RT_COLD_BOUNCE * RT_MFMA_MAX_THREADS + threadIdx.x];
+            j = (int)cold_w[RT_COLD_J * RT_MFMA_MAX_THREADS + threadIdx.x];
+#if RT_COLD_N > 8
+            pxy = cold_w[RT_COLD_PXY * RT_MFMA_MAX_THREADS + threadIdx.x];
+#endif
+#if RT_COLD_N > 9
+            nrays = cold_w[RT_COLD_NRAYS * RT_MFMA_MAX_THREADS + threadIdx.x];
+#endif
+        }
         if (tracing) {
             // a camera ray that went through the sieve (no list for its tile): its hit serves the pixel's other frames
             const bool first = !RECORD && P.cam_reuse != 0 && p.bounce == 0;
@@ -2273,7 +2480,8 @@ __global__ void __launch_bounds__(MODE == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MA
         atomicAdd(slot + 13, 1ull);
     }
 #endif
-    if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave, nlist);
+    // (the camera rays served by P.cam_hits are a path each: the host counts them)
+    if constexpr (!RECORD) add_rays(P, nrays, blockIdx.x * (blockDim.x >> 6) + (unsigned)wave);
 #ifdef RT_COUNT_PASSES
     if (lane == 0)
         atomicAdd(P.rays + ((blockIdx.x * (blockDim.x >> 6) + (unsigned)wave) % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 1,
@@ -2516,6 +2724,16 @@ __global__ void rt_math_probe_kernel(int op, const float* a, const float* b, con
 template <bool FUSED, bool RECORD, int MODE>
 static hipError_t launch_stream(const RtParams& P, int blocks, int threads, size_t lds, hipStream_t st)
 {
+    if constexpr (!RECORD && (MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5 || MODE == 7)) {
+        if (P.split_count != nullptr) {  // heavy tiles in runs of frames
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD, MODE + RT_STREAM_SPLIT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((rt_stream_kernel<FUSED, RECORD, MODE + RT_STREAM_SPLIT>), dim3(blocks), dim3(threads), lds, st, P);
+            return hipGetLastError();
+        }
+    }
+    if (P.split_count != nullptr) return hipErrorInvalidValue;  // no such instantiation
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_stream_kernel<FUSED, RECORD, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2534,7 +2752,9 @@ size_t rt_stream_lds_bytes(int n_lds, int threads, bool mfma, int extra_float4, 
 {
     return (size_t)n_lds * (sizeof(float4) + sizeof(float) + (mfma ? 4 * sizeof(uint4) : 0)) +
            (size_t)extra_float4 * sizeof(float4) + (size_t)n_table * 2 * sizeof(float4) +
-           (size_t)(threads / 64) * (sg_wide ? RT_SG_CHUNKS_WIDE : RT_SG_CHUNKS) * 64 * sizeof(uint32_t);
+           (size_t)(threads / 64) * (sg_wide ? RT_SG_CHUNKS_WIDE : RT_SG_CHUNKS) * 64 * sizeof(uint32_t) +
+           // the instantiation for three waves per SIMD keeps ten words of every lane here while the lane's ray is traced
+           (mfma && threads > RT_STREAM_MAX_THREADS ? (size_t)RT_MFMA_MAX_THREADS * RT_COLD_WORDS * sizeof(uint32_t) : 0);
 }
 
 // mode: 0 = sieve from LDS, 1 = sieve through the scalar cache, 2 = culled (P.bounds/P.perm set, P.n_lds != 0),
@@ -2633,19 +2853,47 @@ size_t rt_lite_handover_bytes(unsigned waves, int ways, int split_frames)
     return (size_t)(waves - waves / (unsigned)ways) * (size_t)split_frames * 192u * sizeof(float);
 }
 
-hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, hipStream_t st)
+hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, unsigned long long* live, hipStream_t st)
 {
     const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows;
     if (fused)
-        hipLaunchKernelGGL((rt_camera_hits_kernel<true>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, hits);
+        hipLaunchKernelGGL((rt_camera_hits_kernel<true>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, hits, live);
     else
-        hipLaunchKernelGGL((rt_camera_hits_kernel<false>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, hits);
+        hipLaunchKernelGGL((rt_camera_hits_kernel<false>), dim3((tiles + 3) / 4), dim3(256), 0, st, P, hits, live);
     return hipGetLastError();
 }
 
-hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, hipStream_t st)
+hipError_t rt_launch_sky_frames(const RtParams& P, bool fused, hipStream_t st)
 {
-    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, st, cost, order, n);
+    const unsigned tiles = (unsigned)P.tile_cols * (unsigned)P.tile_rows;
+    const unsigned blocks = std::min((tiles + 3u) / 4u, 2048u);
+    if (fused)
+        hipLaunchKernelGGL((rt_sky_frames_kernel<true>), dim3(blocks), dim3(256), 0, st, P);
+    else
+        hipLaunchKernelGGL((rt_sky_frames_kernel<false>), dim3(blocks), dim3(256), 0, st, P);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, unsigned nwaves, unsigned heavy_den,
+                                hipStream_t st)
+{
+    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, st, cost, order, n, nwaves, heavy_den);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_tile_units(uint32_t* order, uint4* units, unsigned n, unsigned cap, int ways, int frames, int n_frames,
+                                hipStream_t st)
+{
+    const unsigned most = n + cap * (unsigned)(ways - 1);
+    hipLaunchKernelGGL(rt_tile_units_kernel, dim3((most + 255) / 256), dim3(256), 0, st, order, units, n, cap, (unsigned)ways,
+                       (unsigned)frames, (unsigned)n_frames);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_stream_join(const RtParams& P, hipStream_t st)
+{
+    // (a wave per tile that may have been split; those beyond the order kernel's count return at once)
+    hipLaunchKernelGGL(rt_lite_join_kernel, dim3((P.split_tiles + 3) / 4), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 

@@ -136,6 +136,8 @@ struct RtParams {
     const uint32_t* tile_order;  // lite and stream kernels: k-th tile handed out -> tile of the dispatched region
                                  // (tiles in descending order of their cost in the previous dispatch), or null:
                                  // image order
+    const unsigned long long* cam_live;  // with cam_hits: per tile of the region, the pixels whose camera ray meets a sphere;
+                                 // the stream kernel traces those, rt_sky_frames_kernel finishes the others
     const uint2* cam_hits;       // stream kernel: per pixel of the dispatched region, [tile][pixel of the tile], the nearest
                                  // hit of its camera ray {sphere index or -1, bits of t} (rt_camera_hits_kernel); null: none
     int cam_reuse;               // stream kernel: != 0: the nearest hit of a pixel's camera ray (the same ray in every frame) is
@@ -148,6 +150,12 @@ struct RtParams {
     int split_lds;               // != 0: the runs of a tile are waves of one workgroup and hand their lights to the first run
                                  // through LDS, which joins them at the end of the kernel; 0: through split_lights and
                                  // rt_lite_join_kernel
+    const uint32_t* split_count; // stream kernel: device word holding the number of leading tiles of tile_order whose frames
+                                 // are shared among split_ways units of work (at most split_tiles of them count); null:
+                                 // lite kernel (split_tiles itself) or no split
+    const uint4* split_units;    // stream kernel: the units of work of the dispatch in the order they are handed out
+                                 // (rt_tile_units_kernel): {tile, first frame, end frame, RT_PARK_*}; their number follows
+                                 // the word at split_count
     float4* split_lights;        // the light of every path of the runs after a tile's first:
                                  // [tile of the order][run - 1][frame of the run][pixel of the tile]
     uint32_t* tile_cost;         // rays of each tile in this dispatch are left here (may be null): stored by the

@@ -222,6 +222,12 @@ class Renderer:
         N.check(N.lib().rt_get_sieve_mode(self._h, C.byref(m)))
         return int(m.value)
 
+    def split_info(self) -> dict:
+        """How the last stream-kernel dispatch shared the frames of heavy tiles (rt_debug_split_info)."""
+        out = (C.c_int * 4)()
+        N.check(N.lib().rt_debug_split_info(self._h, out))
+        return dict(zip(("ways", "frames", "most_tiles", "tiles"), (int(x) for x in out)))
+
     def sieve_audit(self, rays: np.ndarray) -> dict:
         """rays: (n, 6) float32 origin+direction; see rt_debug_sieve_audit in include/rt_hip.h."""
         arr = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -775,6 +775,47 @@ def test_full_size_4k_stream_equals_tile(rt, rtiow_scene, pname, profile):
         assert np.array_equal(c_stream3[1200:1216], ccol[1200:1216])
 
 
+@pytest.mark.parametrize("pname,profile", PROFILES)
+def test_frames_of_heavy_tiles_in_runs_stream_kernel(rt, rtiow_scene, pname, profile):
+    """1920x1080, ~500 spheres, 8 frames a dispatch: ten tiles per wave of the stream kernel, so from the
+    dispatch that has an order of the tiles on, the heavy ones (glass and metal, whose pixels bounce long in
+    every frame) are traced in runs of frames by several units of work and joined in frame order.  Three
+    accumulating dispatches (image order; sorted and split; order reused), the second and third with a
+    frame count that makes the last run shorter than the others, against the tile kernel over the whole
+    image, the ray counts, and the oracle on a row of tiles."""
+    w, h = 1920, 1080
+    frames = (8, 7, 7)
+    out = {}
+    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
+        with rt.Renderer(w, h) as r:
+            r.set_profile(profile)
+            r.set_kernel(kernel)
+            r.upload_spheres(rtiow_scene.spheres)
+            first = 3  # no clear: the accumulation image starts with what write_accum put there
+            r.write_accum(np.full((h, w, 4), 0.25, np.float32))
+            for k, n in enumerate(frames):
+                u = rtiow_scene.camera.copy()
+                u["frameCount"][0] = first
+                r.set_uniforms(u)
+                r.dispatch(n)
+                first += n
+                if kernel == rt.KERNEL_STREAM:
+                    info = r.split_info()
+                    assert r.sieve_mode() == 3 and r.info()["threads"] == 768
+                    if k == 0:
+                        assert info["tiles"] == 0
+                    else:
+                        assert info["ways"] == 4 and info["frames"] == 2 and 0 < info["tiles"] <= info["most_tiles"], info
+            out[kernel] = (r.read_accum(), r.read_color(), r.counters()["rays"])
+    a, b = out[rt.KERNEL_STREAM], out[rt.KERNEL_TILE]
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    u = rtiow_scene.camera.copy()
+    u["frameCount"][0] = 3
+    cacc, ccol, _ = O.render(u, rtiow_scene.spheres, w, h, profile=profile, n_frames=sum(frames), rows=(80, 81), threads=8,
+                             accum=np.full((h, w, 4), 0.25, np.float32))
+    assert np.array_equal(_bits(a[0][640:648]), _bits(cacc[640:648])) and np.array_equal(a[1][640:648], ccol[640:648])
+
+
 def test_stress_4096_spheres_as_the_benchmark_runs_it(rt):
     """The 4096-sphere configuration through the path its benchmark takes: matrix-core sieve with the
     operands streamed from L2, candidate walks every 1024 spheres, camera hits, and from the second

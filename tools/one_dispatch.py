@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A few timed dispatches of one workload (development aid for counter collection):
    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 tools/one_dispatch.py [scene W H frames depth kernel reps sphereCount frame0]
-scene: rtiow | default | cubeN.  The first dispatch is a warm-up; the counters printed are those
+scene: rtiow | default | cubeN.  The first three dispatches are a warm-up; the counters printed are those
 of the `reps` timed dispatches."""
 import os
 import sys
@@ -37,7 +37,8 @@ with rt.Renderer(w, h) as r:
         ubo["sphereCount"][0] = count
         ubo["frameCount"][0] = frame0
         r.set_uniforms(ubo)
-    r.dispatch(frames)
+    for _ in range(3):  # the first leaves tile costs, the second sorts by them and allocates what a split needs
+        r.dispatch(frames)
     r.sync()
     r.reset_counters()
     r.timer_begin()
