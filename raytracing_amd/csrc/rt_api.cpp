@@ -92,6 +92,7 @@ struct rt_context {
     // lite kernel: rays per tile of its last dispatch, and the tile order made from them for the next one
     uint32_t* d_tile_cost = nullptr;
     uint32_t* d_tile_order = nullptr;
+    uint32_t* d_tile_chain = nullptr;  // stream kernel: the most rays a pixel of the tile took (behind d_tile_cost, one allocation)
     unsigned tile_cap = 0;       // tiles both arrays have room for
     unsigned cost_tiles = 0;     // tiles d_tile_cost describes (0: nothing yet), for the region below
     uint2* d_cam_hits = nullptr;       // per pixel, the nearest hit of its camera ray (use_camera_hits)
@@ -678,6 +679,7 @@ int env_int(const char* name, int fallback) { return rt_dev_knob(name, fallback)
 void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, int uses = 8, unsigned nwaves = 0,
                     unsigned heavy_den = 1)
 {
+    P.tile_chain = nullptr;
     static const int uses_env = env_int("RT_DEBUG_LPT_USES", 0);  // development knob
     if (uses_env > 0) uses = uses_env;
     const unsigned ntiles = P.total_pixels / 64u;
@@ -689,9 +691,10 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
         if (c->d_tile_order) (void)hipFree(c->d_tile_order);
         c->d_tile_cost = c->d_tile_order = nullptr;
         c->tile_cap = c->cost_tiles = c->order_tiles = 0;
-        if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 4) == hipSuccess &&
+        if (hipMalloc(&c->d_tile_cost, (size_t)ntiles * 8) == hipSuccess &&  // (costs, then chains)
             hipMalloc(&c->d_tile_order, ((size_t)ntiles + 2) * 4) == hipSuccess) {  // (+ the numbers of heavy tiles and of units)
             c->tile_cap = ntiles;
+            c->d_tile_chain = c->d_tile_cost + ntiles;
         } else {
             if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
             c->d_tile_cost = c->d_tile_order = nullptr;
@@ -706,7 +709,8 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
             c->order_uses++;
             P.tile_order = c->d_tile_order;
         } else if (c->cost_tiles == ntiles &&
-                   rt_launch_tile_order(c->d_tile_cost, c->d_tile_order, ntiles, nwaves, heavy_den, c->stream) == hipSuccess) {
+                   rt_launch_tile_order(c->d_tile_cost, zero_cost ? c->d_tile_chain : nullptr, c->d_tile_order, ntiles, nwaves,
+                                        heavy_den, c->stream) == hipSuccess) {
             c->order_tiles = ntiles;
             c->order_uses = 1;
             c->order_serial++;
@@ -718,9 +722,11 @@ void use_tile_order(rt_context* c, RtParams& P, bool order_now, bool zero_cost, 
     c->cost_tiles = 0;
     // will the next dispatch of this region sort?  (it may also not ask for an order at all: then the costs are unused)
     const bool wanted = c->order_tiles != ntiles || c->order_uses >= uses;
-    if (zero_cost && (!wanted || hipMemsetAsync(c->d_tile_cost, 0, (size_t)ntiles * 4, c->stream) != hipSuccess))
+    // (the stream kernel: costs and chains, one behind the other while the capacity is what this region needs)
+    if (zero_cost && (!wanted || hipMemsetAsync(c->d_tile_cost, 0, (size_t)c->tile_cap * 8, c->stream) != hipSuccess))
         return;
     P.tile_cost = c->d_tile_cost;
+    P.tile_chain = c->d_tile_chain;
     c->cost_tiles = ntiles;  // valid once this dispatch has run (the stream is in order)
 }
 
@@ -846,7 +852,8 @@ void use_stream_split(rt_context* c, RtParams& P, int ways_max)
     P.split_units = nullptr;
     if (ways_max < 2 || P.tile_order == nullptr || P.n_frames < 2) return;
     const unsigned ntiles = P.total_pixels / 64u;
-    const int frames = (P.n_frames + std::min(ways_max, P.n_frames) - 1) / std::min(ways_max, P.n_frames);
+    int frames = 1;  // a power of two: the kernel finds the end of a run by its low bits
+    while (frames * std::min(ways_max, P.n_frames) < P.n_frames) frames *= 2;
     const int ways = (P.n_frames + frames - 1) / frames;  // every run holds a frame
     if (ways < 2) return;
     const size_t per_tile = (size_t)ways * (size_t)frames * 64u * sizeof(float4);
@@ -993,17 +1000,24 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
     static const int lpt_min_spheres = env_int("RT_DEBUG_LPT_STREAM_SPHERES", 0);  // development knob; < 0: never
     if (!record && mode != 6 && lpt_min_spheres >= 0 && P.sphere_count >= lpt_min_spheres &&
         (long long)P.total_pixels * P.n_frames >= (1 << 22)) {
-        // Several frames of an image of few tiles per wave: the heavy tiles in runs of frames (use_stream_split).  A tile is
-        // heavy from 1 / split_den of the passes an average wave of the dispatch makes.  Measured on the 484-sphere scene,
-        // 8 frames, without / with: 1920x1080 (10 tiles per wave) 2.31 -> 1.90 ms, 2560x1440 (19) 3.03 -> 2.90 ms,
-        // 3840x2160 (42) 5.47 -> 5.60 ms (nothing left to gain at the end of the dispatch, and the instantiation that
-        // can park lights is 2 % slower); 4096 spheres at 3840x2160 x 2 frames 7.55 -> 7.45 ms.
-        static const int split_den = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_DEN", 8);      // 0 = never
-        static const int split_ways = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_WAYS", 4);
-        static const int split_tiles = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_TILES", 24);  // tiles per wave up to which
+        // The order is by the longest pixel of a tile (rt_tile_order_kernel: a lane takes a pixel at a time, and a pixel's
+        // frames x bounces are one chain).  Several frames a dispatch: the heavy tiles in runs of frames
+        // (use_stream_split): the tiles with a pixel whose rays in the dispatch before were more than 1 / split_den of the
+        // passes of an average wave.  Measured, order by the tile's rays / by its longest pixel / and heavy tiles in
+        // runs (ms): 484 spheres x 8 frames 1920x1080 2.31 / 2.40 / 1.60, 1280x720 x 32 frames - / 7.95 / 3.85; 1000
+        // spheres 1920x1080 x 8 6.7 / 6.3 / 3.75; 4096 spheres 1920x1080 x 4 12.9 / 12.8 / 3.7, 2560x1440 x 2 7.0 / 6.9 /
+        // 3.75, 3840x2160 x 2 7.6 / 7.5 / 6.55; 100 spheres 1280x720 x 16 0.73 / 0.74 / 0.44, 1920x1080 x 32 1.73 / 1.65 /
+        // 1.37; 200 spheres 3840x2160 x 8 2.52 / 2.20 / 2.26.  1 / 4 and 1 / 8 measure the same, 1 / 2 less; 8 runs a tile
+        // as 4, or up to 3 % better.
+        static const int split_den = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_DEN", 4);   // 0: never
+        static const int split_ways = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_WAYS", 8);
         const unsigned nwaves = (unsigned)blocks * (unsigned)threads / 64u;
-        const bool split = split_den > 0 && (mode == 0 || mode == 1 || mode == 3 || mode == 5) &&
-                           P.total_pixels / 64u <= (unsigned)split_tiles * nwaves;
+        // (images of many tiles per wave end on a short note by themselves, and the instantiation that can park lights is 2 %
+        // slower: 484 spheres 3840x2160 x 8 frames, 42 tiles per wave, 5.28 -> 5.36 ms; but 4096 spheres, 63 tiles per
+        // wave of the kernel that streams its operands from L2, 7.50 -> 6.55 ms)
+        static const int split_tiles = rt_dev_knob("RT_DEBUG_STREAM_SPLIT_TILES", 24);
+        const bool split = split_den > 0 && P.n_frames >= 2 && (mode == 0 || mode == 1 || mode == 3 || mode == 5) &&
+                           (mode == 5 || P.total_pixels / 64u <= (unsigned)split_tiles * nwaves);
         use_tile_order(c, P, true, true, 8, split ? nwaves : 0u, (unsigned)std::max(1, split_den));
         if (split) use_stream_split(c, P, split_ways);
     }

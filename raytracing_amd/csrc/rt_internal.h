@@ -18,8 +18,8 @@ hipError_t rt_launch_lite(const RtParams& P, bool fused, int threads, hipStream_
 size_t rt_lite_handover_bytes(unsigned waves, int ways, int split_frames);
 hipError_t rt_launch_camera_hits(const RtParams& P, bool fused, uint2* hits, unsigned long long* live, hipStream_t st);
 hipError_t rt_launch_sky_frames(const RtParams& P, bool fused, hipStream_t st);
-hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, unsigned nwaves, unsigned heavy_den,
-                                hipStream_t st);
+hipError_t rt_launch_tile_order(const uint32_t* cost, const uint32_t* chain, uint32_t* order, unsigned n, unsigned nwaves,
+                                unsigned heavy_den, hipStream_t st);
 hipError_t rt_launch_stream_join(const RtParams& P, hipStream_t st);
 hipError_t rt_launch_tile_units(uint32_t* order, uint4* units, unsigned n, unsigned cap, int ways, int frames, int n_frames,
                                 hipStream_t st);

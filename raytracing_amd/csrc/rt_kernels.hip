@@ -1031,27 +1031,31 @@ __global__ void __launch_bounds__(256) rt_lite_join_kernel(const RtParams P)
 // waiting for them (measured: 25 % of the vector ALU idle at 1080p x 64 frames).  Longest first,
 // they start at once and the light ones fill in behind.  The order only says who goes first: the
 // bits of the image cannot depend on it.  One workgroup of 1024 threads; n = number of tiles.
-// order[n] = the number of leading tiles of the order that are HEAVY: whose rays, traced 64 at a time by one wave,
-// are more passes than 1 / heavy_den of what an average wave of `nwaves` traces in the whole dispatch (0 with
-// nwaves == 0).  The stream kernel shares the frames of those tiles among several waves (RtParams::split_*).
-__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cost, uint32_t* order, unsigned n,
-                                                             unsigned nwaves, unsigned heavy_den)
+// chain != null (stream kernel): the order is by chain[tile] instead, the most rays any pixel of the tile took in that
+// dispatch: there a lane takes one pixel at a time, and what a dispatch ends waiting for is a pixel's chain of
+// frames x bounces, started late.  order[n] = the number of leading tiles of that order that are HEAVY: whose
+// longest pixel is more passes (a ray a pass) than 1 / heavy_den of what an average wave of `nwaves` makes in the whole
+// dispatch, the sum of `cost` / (64 nwaves).  The stream kernel shares the frames of those tiles among several units
+// of work (RtParams::split_*).  0 with nwaves == 0.
+__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cost, const uint32_t* chain, uint32_t* order,
+                                                             unsigned n, unsigned nwaves, unsigned heavy_den)
 {
     __shared__ unsigned s_max;
     __shared__ unsigned s_bin[256];
     __shared__ unsigned long long s_sum;
     __shared__ unsigned s_heavy;
+    const uint32_t* key = chain != nullptr ? chain : cost;
     if (threadIdx.x == 0) {
         s_sum = 0ull;
         s_heavy = 0u;
+        s_max = 1u;
     }
-    if (threadIdx.x == 0) s_max = 1u;
     if (threadIdx.x < 256) s_bin[threadIdx.x] = 0u;
     __syncthreads();
     unsigned m = 0;
     unsigned long long sum = 0ull;
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-        m = max(m, cost[i]);
+        m = max(m, key[i]);
         sum += cost[i];
     }
     atomicMax(&s_max, m);
@@ -1059,7 +1063,7 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
     __syncthreads();
     const float scale = 255.0f / (float)s_max;
     auto cls = [&](unsigned c) { return 255u - min(255u, (unsigned)((float)c * scale)); };  // class 0 = heaviest
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_bin[cls(cost[i])], 1u);
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_bin[cls(key[i])], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {  // exclusive prefix: where each class begins
         unsigned at = 0;
@@ -1070,12 +1074,15 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
         }
     }
     __syncthreads();
-    // heavy: cost / 64 passes >= (sum / 64 / nwaves) / heavy_den
-    const unsigned long long heavy_from = nwaves != 0u ? s_sum / ((unsigned long long)nwaves * heavy_den) + 1ull : ~0ull;
+    // heavy: chain passes >= (sum / 64 / nwaves) / heavy_den -- by cost class, so that the heavy tiles lead the order
+    const unsigned long long heavy_from =
+        nwaves != 0u && chain != nullptr ? s_sum / (64ull * nwaves * heavy_den) + 1ull : ~0ull;
+    const unsigned heavy_cls = heavy_from <= (unsigned long long)s_max ? cls((unsigned)heavy_from) : 0u;
     unsigned heavy = 0;
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-        order[atomicAdd(&s_bin[cls(cost[i])], 1u)] = i;
-        heavy += cost[i] >= heavy_from ? 1u : 0u;
+        const unsigned c = cls(key[i]);
+        order[atomicAdd(&s_bin[c], 1u)] = i;
+        heavy += heavy_from <= (unsigned long long)s_max && c < heavy_cls ? 1u : 0u;
     }
     if (heavy != 0u) atomicAdd(&s_heavy, heavy);
     __syncthreads();
@@ -1092,9 +1099,9 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* cos
 #define RT_PARK_NONE 2u
 
 // The units of work of a dispatch of the stream kernel that shares the frames of heavy tiles, in the order they are
-// handed out: `ways` runs of `frames` frames for each of the first S tiles of the order (S = order[n], the heavy tiles
-// rt_tile_order_kernel counted, at most `cap`), then the other tiles with all their frames.  units[u] = {tile, first
-// frame, end frame, RT_PARK_*: for a run after a tile's first, 4 x the index in the parked lights of the light of
+// handed out: `ways` runs of `frames` frames (a power of two) for each of the first S tiles of the order (S = order[n],
+// the heavy tiles rt_tile_order_kernel counted, at most `cap`), then the other tiles with all their frames.  units[u] =
+// {tile, first frame, end frame, RT_PARK_*: for a run after a tile's first, 4 x the index in the parked lights of the light of
 // lane 0's frame 0}; order[n + 1] = the number of units.  One thread per unit, n + cap * (ways - 1) at least.
 __global__ void __launch_bounds__(256) rt_tile_units_kernel(uint32_t* order, uint4* units, unsigned n, unsigned cap, unsigned ways,
                                                             unsigned frames, unsigned n_frames)
@@ -1926,7 +1933,8 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
             if constexpr (RECORD) record_light(P, px, py, j, p);                                                            \
             /* the end of the lane's frames: the last frame, or the last of its run of a split tile */                      \
             const int jn = j + 1;                                                                                           \
-            const bool last = jn == (SPLIT ? jend : P.n_frames);                                                            \
+            /* (a run of a split tile is split_frames frames, a power of two, from a multiple of it) */                    \
+            const bool last = jn == P.n_frames || (SPLIT && park != RT_PARK_NONE && (jn & (P.split_frames - 1)) == 0);      \
             if (SPLIT && (park & 3u) == RT_PARK_LATER) { /* a run after a split tile's first: the light waits for the join */ \
                 P.split_lights[(park >> 2) + (uint32_t)j * 64u] = make_float4(p.lr, p.lg, p.lb, 0.f);                       \
             } else {                                                                                                        \
@@ -1948,10 +1956,13 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
             j = jn;                                                                                                         \
             if (last) {                                                                                                     \
                 if constexpr (!RECORD) {                                                                                    \
-                    if (P.tile_cost != nullptr) /* the pixel's rays go to its tile's cost, for the next dispatch's order */ \
-                        atomicAdd(P.tile_cost + ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +               \
-                                      ((px >> 3) - (uint32_t)P.tile_col0),                                                  \
-                                  nrays - pixel_rays0);                                                                     \
+                    if (P.tile_cost != nullptr) { /* the pixel's rays: its tile's cost and chain, for the next order */    \
+                        const uint32_t t_ = ((py >> 3) - (uint32_t)P.tile_row0) * (uint32_t)P.tile_cols +                   \
+                                            ((px >> 3) - (uint32_t)P.tile_col0);                                            \
+                        atomicAdd(P.tile_cost + t_, nrays - pixel_rays0);                                                   \
+                        /* (a run of a split tile: as many rays as the whole pixel would have taken, near enough) */        \
+                        atomicMax(P.tile_chain + t_, (nrays - pixel_rays0) * (SPLIT && park != RT_PARK_NONE ? (uint32_t)P.split_ways : 1u)); \
+                    }                                                                                                       \
                 }                                                                                                           \
                 alive = false;                                                                                              \
             } else {                                                                                                        \
@@ -1968,7 +1979,7 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
         const uint32_t px = pxy & 0xffffu, py = pxy >> 16;                                                          \
         path_reset(p, P, d0x, d0y, d0z);                                                                            \
         (void)path_bounce<FUSED, false>(p, P, -1, RT_FLT_MAX, px, py, 0u, nullptr, nullptr);                        \
-        const int jstop = SPLIT ? jend : P.n_frames;                                                                \
+        const int jstop = SPLIT && park != RT_PARK_NONE ? min(P.n_frames, j + P.split_frames) : P.n_frames;         \
         const unsigned left = (unsigned)(jstop - j);                                                                \
         for (; j < jstop; j++) {                                                                                    \
             if (SPLIT && (park & 3u) == RT_PARK_LATER) {                                                            \
@@ -2069,9 +2080,9 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
     // the wave's unit of work: the pixels of its tile not yet handed to a lane, the tile, SPLIT: its run of frames
     unsigned long long avail = 0ull;
     uint32_t span_tile = 0;
-    int span_j0 = 0, span_jend = 0;
+    int span_j0 = 0;
     uint32_t span_park = RT_PARK_NONE;
-    (void)span_j0; (void)span_jend; (void)span_park;
+    (void)span_j0; (void)span_park;
     bool exhausted = false;
     auto queue_len = [&](uint32_t q) -> uint32_t { return (nspans + RT_QUEUES - 1 - q) / RT_QUEUES; };
     // Lane 0 asks a queue for its next span; the answer is left in a vector register so that
@@ -2107,7 +2118,6 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
     int j = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned nrays = 0, pixel_rays0 = 0;  // rays of this lane so far; their count when its pixel began
-    int jend = 0;                   // SPLIT: the lane's frames end here
     uint32_t park = RT_PARK_NONE;   // SPLIT: see RT_PARK_NONE
 #ifdef RT_COUNT_PASSES
     unsigned npasses = 0;  // experiment: passes over the sphere list, added to the word after the ray counter
@@ -2166,7 +2176,6 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
                     const uint4 unit = P.split_units[slot];
                     span_tile = __builtin_amdgcn_readfirstlane(unit.x);
                     span_j0 = (int)__builtin_amdgcn_readfirstlane(unit.y);
-                    span_jend = (int)__builtin_amdgcn_readfirstlane(unit.z);
                     span_park = __builtin_amdgcn_readfirstlane(unit.w);
                 } else {  // heaviest tiles of the previous dispatch first when their costs are known
                     span_tile = P.tile_order != nullptr ? __builtin_amdgcn_readfirstlane(P.tile_order[slot]) : slot;
@@ -2199,7 +2208,6 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
                 j = 0;
                 if constexpr (SPLIT) {
                     j = span_j0;
-                    jend = span_jend;
                     park = span_park + ((span_park & 3u) == RT_PARK_LATER ? l << 2 : 0u);
                 }
                 // tile / tile_cols by multiplication: exact for tile < 2^24 (checked on the host)
@@ -2874,10 +2882,10 @@ hipError_t rt_launch_sky_frames(const RtParams& P, bool fused, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, unsigned n, unsigned nwaves, unsigned heavy_den,
-                                hipStream_t st)
+hipError_t rt_launch_tile_order(const uint32_t* cost, const uint32_t* chain, uint32_t* order, unsigned n, unsigned nwaves,
+                                unsigned heavy_den, hipStream_t st)
 {
-    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, st, cost, order, n, nwaves, heavy_den);
+    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, st, cost, chain, order, n, nwaves, heavy_den);
     return hipGetLastError();
 }
 

@@ -160,6 +160,7 @@ struct RtParams {
                                  // [tile of the order][run - 1][frame of the run][pixel of the tile]
     uint32_t* tile_cost;         // rays of each tile in this dispatch are left here (may be null): stored by the
                                  // lite kernel, added pixel by pixel by the stream kernel (zeroed before the launch)
+    uint32_t* tile_chain;        // stream kernel, with tile_cost: the most rays a pixel of each tile took (zeroed before the launch)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
     unsigned* work_counter;      // RT_WORK_BYTES block of queue counters; all zero between launches

@@ -15,6 +15,7 @@ for rep in 1 2; do
   run head variants/libhead.so X=1
   run nosplit variants/libknobs.so RT_DEBUG_STREAM_SPLIT_DEN=0
   for cfg in ${RT_AB_CFG:-4:8 2:8 8:8 4:4 4:2}; do
-    run "den${cfg%%:*}_ways${cfg##*:}" variants/libknobs.so RT_DEBUG_STREAM_SPLIT_DEN=${cfg%%:*} RT_DEBUG_STREAM_SPLIT_WAYS=${cfg##*:}
+    IFS=: read -r den ways tiles <<< "$cfg"
+    run "den${den}_ways${ways}_tiles${tiles:-24}" variants/libknobs.so RT_DEBUG_STREAM_SPLIT_DEN=$den RT_DEBUG_STREAM_SPLIT_WAYS=$ways RT_DEBUG_STREAM_SPLIT_TILES=${tiles:-24}
   done
 done
