@@ -21,6 +21,14 @@ echo "$args" > "$out/bench_args.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
     python3 bench.py $args > "$out/bench_stats.log" 2>&1
 grep '^{' "$out/bench_stats.log" > "$out/bench_line.json"
+# RT_COLLECT_LINES_ONLY=1: only the profiled and the plain bench line again (second pass: the lines then quote the
+# counters that the first pass put into profiles/<tag>_pmc.json)
+if [ -n "$RT_COLLECT_LINES_ONLY" ]; then
+  timeout -k 10 300 python3 bench.py $args > "$out/bench_plain.log" 2>&1
+  grep '^{' "$out/bench_plain.log" > "$out/bench_line_plain.json"
+  echo "collected lines of $label"
+  exit 0
+fi
 timeout -s KILL 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o bench -- \
     python3 bench.py $args > "$out/bench_fetch.log" 2>&1
 timeout -s KILL 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o bench -- \

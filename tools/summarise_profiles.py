@@ -31,16 +31,29 @@ KERNELS = ("rt_stream_kernel", "rt_tile_kernel", "rt_lite_kernel")
 
 
 def per_launch(path, timed):
-    """{counter: mean over the last `timed` launches}, mean duration (ns) of those launches, kernel name."""
-    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in KERNELS)]
+    """{counter: mean over the last `timed` launches}, mean duration (ns) of those launches, kernel name.
+    A step of the stream kernel also launches small kernels of the library (rt_sky_frames_kernel for the pixels that
+    see the sky, the join of split tiles, the tile order every eighth step): the bytes they move belong to the step,
+    so FETCH_SIZE and WRITE_SIZE include theirs (summed over the window of the timed launches, per launch);
+    every other counter is the main kernel's alone."""
+    every = list(csv.DictReader(open(path)))
+    rows = [r for r in every if any(k in r["Kernel_Name"] for k in KERNELS)]
     by = collections.defaultdict(list)
     for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
-        by[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        by[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                      int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     out, dur = {}, None
     for name, v in by.items():
+        window_from = v[-timed - 1][3] if len(v) > timed else 0
+        window_to = v[-1][3]
         v = v[-timed:]
-        out[name] = sum(x for x, _ in v) / len(v)
-        dur = sum(d for _, d in v) / len(v)
+        out[name] = sum(x[0] for x in v) / len(v)
+        dur = sum(x[1] for x in v) / len(v)
+        if name in ("FETCH_SIZE", "WRITE_SIZE"):
+            helpers = [r for r in every if r["Counter_Name"] == name and "rt_" in r["Kernel_Name"]
+                       and not any(k in r["Kernel_Name"] for k in KERNELS)
+                       and window_from < int(r["Start_Timestamp"]) <= window_to]
+            out[name] += sum(float(r["Counter_Value"]) for r in helpers) / len(v)
     return out, dur, (rows[0]["Kernel_Name"].split("(")[0] if rows else None)
 
 
@@ -97,6 +110,8 @@ def one(tag, wl, pmc_all):
     json.dump({"command": "python3 bench.py " + open(os.path.join(src, "bench_args.txt")).read().strip(),
                "under_rocprofv3_kernel_trace": line, "unprofiled": plain},
               open(os.path.join(dst, f"{tag}_{wl}_bench_line.json"), "w"), indent=1)
+    if os.environ.get("RT_SUMMARISE_LINES_ONLY"):  # second pass: counters and <tag>_pmc.json stay as the first pass left them
+        return
     timed = int(line["roofline"]["launches"])
     counters, durations, kernel = {}, {}, None
     for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait"):
