@@ -1698,16 +1698,21 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
     uint32_t bm1 = n4 > 8 && alive ? ~rej1 << (32 - 4 * (n4 - 8)) : 0u;
     uint32_t gm = 0;  // bit (31 - k): group k of the open block is still to be visited
     int blk = 0;
+    // Nearer blocks first, roughly: the sorted list runs from the low corner of the scene to the high one (median
+    // splits along the longest axis, the lower half first), so a ray that travels towards the low corner visits
+    // blocks and groups from the far end of the list.  The sooner a near hit is known, the more the distance test
+    // drops: 484 spheres at 3840x2160 4.79 -> 4.11 ms a dispatch, 4096 spheres 4.68 -> 4.01, 1000 spheres 8.5 -> 7.7.
+    const bool rev = (p.dx + p.dy) + p.dz < 0.0f;
     for (;;) {
         // ---- lanes without an open group open their next block
         const bool open = gm == 0u && (bm0 | bm1) != 0u;
         if (__ballot(open) != 0ull) {
             if (open) {
-                if (bm0 != 0u) {
-                    blk = __clz(bm0);
+                if (rev ? bm1 == 0u : bm0 != 0u) {
+                    blk = rev ? 31 - __builtin_ctz(bm0) : __clz(bm0);
                     bm0 &= ~(0x80000000u >> blk);
                 } else {
-                    const int k = __clz(bm1);
+                    const int k = rev ? 31 - __builtin_ctz(bm1) : __clz(bm1);
                     bm1 &= ~(0x80000000u >> k);
                     blk = 32 + k;
                 }
@@ -1739,7 +1744,7 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
         int grp = 0;
         uint32_t cand = 0u;
         if (leaf) {
-            const int k = __clz(gm);
+            const int k = rev ? 31 - __builtin_ctz(gm) : __clz(gm);
             gm &= ~(0x80000000u >> k);
             grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + k;
             const v4f* g = geom + grp * RT_CULL_GROUP;
