@@ -114,6 +114,7 @@ struct rt_context {
     int* d_perm = nullptr;        // sorted slot -> index in d_spheres
     int cull_cap = 0;             // slots allocated
     int cull_count = -1;          // sphere_count the sorted copy was built for; -1 = none / stale
+    uint32_t kd_axes = 0;         // CulledScene::kd_axes of that copy
 
     int last_blocks = 0, last_threads = 0; // geometry of the last stream-kernel launch
     int last_mode = -1;                    // and its sieve: the values of rt_get_sieve_mode
@@ -356,6 +357,8 @@ struct CulledScene {
     std::vector<float> bounds;  // 4 floats per group, pair-packed, padded to 64 groups
     std::vector<float> boxes;   // per-lane traversal: 6 floats per group, then per block (see build_boxes)
     std::vector<int> perm;      // per slot
+    uint32_t kd_axes = 0;       // two bits per bit 3.. of a slot number: the axis along which the halves of the list that
+                                // differ in that bit were split (the one most spheres were split by), see build_culled
 };
 
 void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, CulledScene* out)
@@ -384,45 +387,57 @@ void build_culled(const std::vector<RtSphereAos>& src, int count, int n_pad, Cul
         else
             rest.push_back(i);
     }
-    // The rest: recursive median splits along the longest axis of the centres, cut at the slot
-    // boundaries of superblocks (RT_BVH_SUPER slots) first, then of blocks (RT_BVH_BLOCK) and of groups
-    // (RT_CULL_GROUP) inside them, so that each of them is a compact cell of a k-d partition.  (Runs of a Morton
-    // curve, the first version, are not: 64 consecutive points of a 22 x 22 grid came out as
-    // rectangles up to 22 x 8 that overlapped one another.)
+    // The rest: median splits, the lower half first, cut at slot boundaries: always at the multiple of RT_CULL_GROUP
+    // inside a range whose slot number has the most trailing zero bits, so that superblocks (RT_BVH_SUPER slots), blocks
+    // (RT_BVH_BLOCK) and groups (RT_CULL_GROUP) each are a compact cell of a k-d partition AND the two halves of a split
+    // differ in one bit of the slot number.  All splits that differ in the same bit are along the same axis -- the one
+    // with the largest extent summed over them, weighted by their spheres -- so the traversal turns "nearer half first"
+    // into flipping that bit for a ray that travels towards lower coordinates along that axis (kd_axes).  (Runs of a
+    // Morton curve, the first version, are not compact: 64 consecutive points of a 22 x 22 grid came out as rectangles
+    // up to 22 x 8 that overlapped one another.)
     {
         const int base = (int)keyed.size();  // slot of rest[0]
         auto coord = [&](int i, int axis) { return axis == 0 ? src[i].cx : axis == 1 ? src[i].cy : src[i].cz; };
-        struct Range { int lo, hi, unit; };
-        std::vector<Range> todo{{0, (int)rest.size(), RT_BVH_SUPER}};
-        while (!todo.empty()) {
-            const Range r = todo.back();
-            todo.pop_back();
-            if (r.hi - r.lo <= 1) continue;
-            // slot boundaries (multiples of unit in absolute slots) strictly inside the range
-            const int first = ((base + r.lo) / r.unit + 1) * r.unit - base;
-            const int nb = first < r.hi ? (r.hi - 1 - first) / r.unit + 1 : 0;
-            if (nb == 0) {
-                if (r.unit > RT_CULL_GROUP) todo.push_back({r.lo, r.hi, r.unit == RT_BVH_SUPER ? RT_BVH_BLOCK : RT_CULL_GROUP});
-                else std::sort(rest.begin() + r.lo, rest.begin() + r.hi);  // inside a group: index order
-                continue;
-            }
-            const int mid = first + (nb / 2) * r.unit;
-            float lo3[3] = {inf, inf, inf}, hi3[3] = {-inf, -inf, -inf};
-            for (int k = r.lo; k < r.hi; k++)
+        struct Range { int lo, hi; };
+        std::vector<Range> ranges{{0, (int)rest.size()}};
+        out->kd_axes = 0;
+        for (int tz = 30; tz >= 3; tz--) {
+            const long long step = 1ll << tz;
+            // the ranges with a boundary of this alignment inside (at most one: a second would make one of a higher)
+            std::vector<std::pair<size_t, int>> cut;  // index into ranges, position of the boundary in `rest`
+            double extent[3] = {0.0, 0.0, 0.0};
+            for (size_t n = 0; n < ranges.size(); n++) {
+                const Range r = ranges[n];
+                if (r.hi - r.lo <= 1) continue;
+                const long long s0 = ((long long)(base + r.lo) / step + 1) * step;
+                if (s0 >= base + r.hi) continue;
+                cut.push_back({n, (int)(s0 - base)});
                 for (int a = 0; a < 3; a++) {
-                    lo3[a] = std::min(lo3[a], coord(rest[k], a));
-                    hi3[a] = std::max(hi3[a], coord(rest[k], a));
+                    float lo = inf, hi = -inf;
+                    for (int k = r.lo; k < r.hi; k++) {
+                        lo = std::min(lo, coord(rest[k], a));
+                        hi = std::max(hi, coord(rest[k], a));
+                    }
+                    if (hi >= lo && std::isfinite(hi - lo)) extent[a] += (double)(hi - lo) * (r.hi - r.lo);
                 }
+            }
+            if (cut.empty()) continue;
             int axis = 0;
             for (int a = 1; a < 3; a++)
-                if (hi3[a] - lo3[a] > hi3[axis] - lo3[axis]) axis = a;
-            std::nth_element(rest.begin() + r.lo, rest.begin() + mid, rest.begin() + r.hi, [&](int x, int y) {
-                const float cx = coord(x, axis), cy = coord(y, axis);
-                return cx < cy || (cx == cy && x < y);
-            });
-            todo.push_back({r.lo, mid, r.unit});
-            todo.push_back({mid, r.hi, r.unit});
+                if (extent[a] > extent[axis]) axis = a;
+            if (tz - 3 < 16) out->kd_axes |= (uint32_t)axis << (2 * (tz - 3));
+            for (const auto& c : cut) {
+                const Range r = ranges[c.first];
+                const int mid = c.second;
+                std::nth_element(rest.begin() + r.lo, rest.begin() + mid, rest.begin() + r.hi, [&](int x, int y) {
+                    const float cx = coord(x, axis), cy = coord(y, axis);
+                    return cx < cy || (cx == cy && x < y);
+                });
+                ranges[c.first] = {r.lo, mid};
+                ranges.push_back({mid, r.hi});
+            }
         }
+        for (const Range& r : ranges) std::sort(rest.begin() + r.lo, rest.begin() + r.hi);  // inside a group: index order
         for (int i : rest) keyed.push_back({1u, i});
     }
 
@@ -622,6 +637,7 @@ int ensure_culled(rt_context* c, int count, int n_pad)
     HIP_TRY(hipMemcpy(c->d_boxes, cs.boxes.data(), cs.boxes.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_perm, cs.perm.data(), cs.perm.size() * sizeof(int), hipMemcpyHostToDevice));
     c->cull_count = count;
+    c->kd_axes = cs.kd_axes;
     return RT_OK;
 }
 
@@ -642,6 +658,7 @@ int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false, int max
     P->boxes = c->d_boxes;
     P->n_bounds = (P->n_pad / RT_CULL_GROUP + 63) / 64 * 64;
     P->n_block_boxes = block_boxes(P->n_pad);
+    P->kd_axes = c->kd_axes;
     P->perm = c->d_perm;
     *on = true;
     return RT_OK;

@@ -1636,6 +1636,33 @@ __device__ __forceinline__ float bvh_reach(float best, float a)
     return best * (a * __builtin_amdgcn_rsqf(a));
 }
 
+// A mask of 32 nodes, bit (31 - n) for node n, rearranged so that bit (31 - m) stands for node m ^ f (f < 32; levels:
+// wave-uniform, the bits of f that can be set).  Taking the bits of the result from the top then visits the nodes in
+// ascending order of (number ^ f): with f = the bits whose split a ray crosses downwards, nearer nodes first.
+__device__ __forceinline__ uint32_t bvh_rearrange(uint32_t m, uint32_t f, int levels)
+{
+    if (f & 1u) m = ((m & 0x55555555u) << 1) | ((m >> 1) & 0x55555555u);
+    if (f & 2u) m = ((m & 0x33333333u) << 2) | ((m >> 2) & 0x33333333u);
+    if (f & 4u) m = ((m & 0x0f0f0f0fu) << 4) | ((m >> 4) & 0x0f0f0f0fu);
+    if (levels > 3) {
+        if (f & 8u) m = ((m & 0x00ff00ffu) << 8) | ((m >> 8) & 0x00ff00ffu);
+        if (f & 16u) m = (m << 16) | (m >> 16);
+    }
+    return m;
+}
+
+// The bits of a slot number whose split a ray crosses from the higher coordinates to the lower (RtParams::kd_axes):
+// bit k of the result stands for bit 3 + k of the slot number; n_bits of them (wave-uniform).
+__device__ __forceinline__ uint32_t bvh_flip_bits(const Path& p, uint32_t kd_axes, int n_bits)
+{
+    const uint32_t neg = (p.dx < 0.0f ? 1u : 0u) | (p.dy < 0.0f ? 2u : 0u) | (p.dz < 0.0f ? 4u : 0u);
+    uint32_t flip = 0u;
+#pragma unroll
+    for (int k = 0; k < 13; k++)
+        if (k < n_bits) flip |= ((neg >> ((kd_axes >> (2 * k)) & 3u)) & 1u) << k;
+    return flip;
+}
+
 // (The traversal is a chain of dependent LDS gathers and gains from every wave it can get: 13.9 /
 // 18.9 / 22.9 / 26.3 Grays/s at 4 / 6 / 8 / 12 waves per CU on the 484-sphere scene.  Its ~150
 // registers allow 12; capped at 128 registers for 16 waves it spills 46 of them.)
@@ -1698,34 +1725,56 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
     uint32_t bm1 = n4 > 8 && alive ? ~rej1 << (32 - 4 * (n4 - 8)) : 0u;
     uint32_t gm = 0;  // bit (31 - k): group k of the open block is still to be visited
     int blk = 0;
-    // Nearer blocks first, roughly: the sorted list runs from the low corner of the scene to the high one (median
-    // splits along the longest axis, the lower half first), so a ray that travels towards the low corner visits
-    // blocks and groups from the far end of the list.  The sooner a near hit is known, the more the distance test
-    // drops: 484 spheres at 3840x2160 4.79 -> 4.11 ms a dispatch, 4096 spheres 4.68 -> 4.01, 1000 spheres 8.5 -> 7.7.
-    const bool rev = (p.dx + p.dy) + p.dz < 0.0f;
+    // Nearer blocks and groups first.  The sorted list is a k-d partition whose two halves at every split differ in
+    // one bit of the slot number, the half with the lower coordinates holding the 0 (build_culled): a ray that travels
+    // towards lower coordinates along the axis of a bit meets the half with the 1 first.  flip: those bits; a lane
+    // visits blocks in ascending order of (block number ^ its flip bits) and the groups of a block likewise.  The sooner
+    // a near hit is known, the more the distance test drops.  Measured at 3840x2160, slot order / nearer first (ms a
+    // dispatch): 4096 spheres 4.68 / 3.0, 8192 (out of global memory, trace_bvh_far) 3.9 / 2.35, 16 384 2.40 / 1.76,
+    // 65 536 2.29 / 1.99, 1000 spheres 8.5 / 7.1, 484 spheres on a plane 4.79 / 4.26 (4.11 with one bit for the whole
+    // list, by the sign of dx + dy + dz: there the ~90 instructions a pass that the bits cost outweigh what they add).
+    const int levels = nblk > 32 ? 6 : nblk > 16 ? 5 : nblk > 8 ? 4 : 3;  // bits that number this scene's blocks
+    const uint32_t flip = bvh_flip_bits(p, P.kd_axes, 3 + levels);
+    const uint32_t flip_g = flip & 7u, flip_b = flip >> 3;  // of the group within its block, of the block
+    // the masks of the blocks, bit (31 - n) for block n, rearranged so that bit (31 - m) stands for block m ^ flip_b
+    auto rearrange = [](uint32_t m, uint32_t f, int levels) { return bvh_rearrange(m, f, levels); };
+    bm0 = rearrange(bm0, flip_b, levels);
+    if (levels > 5) {
+        bm1 = rearrange(bm1, flip_b, levels);
+        if (flip_b & 32u) {
+            const uint32_t t_ = bm0;
+            bm0 = bm1;
+            bm1 = t_;
+        }
+    }
     for (;;) {
         // ---- lanes without an open group open their next block
         const bool open = gm == 0u && (bm0 | bm1) != 0u;
         if (__ballot(open) != 0ull) {
             if (open) {
-                if (rev ? bm1 == 0u : bm0 != 0u) {
-                    blk = rev ? 31 - __builtin_ctz(bm0) : __clz(bm0);
+                if (bm0 != 0u) {
+                    blk = __clz(bm0);
                     bm0 &= ~(0x80000000u >> blk);
                 } else {
-                    const int k = rev ? 31 - __builtin_ctz(bm1) : __clz(bm1);
+                    const int k = __clz(bm1);
                     bm1 &= ~(0x80000000u >> k);
                     blk = 32 + k;
                 }
+                blk ^= (int)flip_b;
                 const v4f* g = boxes + blk * (RT_BVH_BLOCK / RT_CULL_GROUP / 2 * 3);  // 8 groups = 4 pairs = 12 float4
-                v4f e[12];
-#pragma unroll
-                for (int k = 0; k < 12; k++) e[k] = g[k];
                 const float reach = bvh_reach(best, a);
                 uint32_t rej = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) bvh_box_pair(rej, e[3 * k], e[3 * k + 1], e[3 * k + 2], br, reach);
+                for (int half = 0; half < 2; half++) {  // (six registers of boxes at a time: this kernel has none to spare)
+                    v4f e[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) e[k] = g[6 * half + k];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) bvh_box_pair(rej, e[3 * k], e[3 * k + 1], e[3 * k + 2], br, reach);
+                }
                 gm = (~rej) << (32 - RT_CULL_GROUP);
                 if (blk == 0) gm &= 0x7fffffffu;  // group 0 has been dealt with
+                gm = rearrange(gm, flip_g, 3);      // bit (31 - m): group m ^ flip_g
             }
 #ifdef RT_COUNT_PASSES
             bvh_steps_ += open ? 0x10001u : 0x10000u;  // experiment: wave steps << 16 | this lane's steps
@@ -1744,9 +1793,9 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
         int grp = 0;
         uint32_t cand = 0u;
         if (leaf) {
-            const int k = rev ? 31 - __builtin_ctz(gm) : __clz(gm);
+            const int k = __clz(gm);
             gm &= ~(0x80000000u >> k);
-            grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + k;
+            grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + (k ^ (int)flip_g);
             const v4f* g = geom + grp * RT_CULL_GROUP;
             v4f e[RT_CULL_GROUP];
 #pragma unroll
@@ -1840,6 +1889,21 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
         }
         sm[w] = alive ? ~rej << (32 - 4 * quads) : 0u;
     }
+    // nearer nodes first (see trace_bvh): groups of a block, blocks of a superblock, superblocks
+    int sup_bits = 0;
+    while ((1 << sup_bits) < nsb) sup_bits++;
+    const uint32_t flip = bvh_flip_bits(p, P.kd_axes, 6 + sup_bits);
+    const uint32_t flip_g = flip & 7u, flip_k = (flip >> 3) & 7u, flip_s = flip >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) sm[w] = bvh_rearrange(sm[w], flip_s & 31u, sup_bits);
+    if (flip_s & 32u) {
+        uint32_t t_ = sm[0]; sm[0] = sm[1]; sm[1] = t_;
+        t_ = sm[2]; sm[2] = sm[3]; sm[3] = t_;
+    }
+    if (flip_s & 64u) {
+        uint32_t t_ = sm[0]; sm[0] = sm[2]; sm[2] = t_;
+        t_ = sm[1]; sm[1] = sm[3]; sm[3] = t_;
+    }
     uint32_t bm = 0, gm = 0;  // blocks of the open superblock / groups of the open block still to be visited
     int sup = 0, blk = 0;
     auto test_boxes = [&](const v4f* g) -> uint32_t {  // 8 boxes = 4 pairs = 12 float4 at the lane's own address
@@ -1863,8 +1927,8 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
                 word &= ~(0x80000000u >> k);
                 sm[0] = w == 0 ? word : sm[0]; sm[1] = w == 1 ? word : sm[1];
                 sm[2] = w == 2 ? word : sm[2]; sm[3] = w == 3 ? word : sm[3];
-                sup = 32 * w + k;
-                bm = test_boxes(block_boxes + sup * 12);
+                sup = (32 * w + k) ^ (int)flip_s;
+                bm = bvh_rearrange(test_boxes(block_boxes + sup * 12), flip_k, 3);
             }
         }
         // ---- lanes without an open group open their next block
@@ -1873,9 +1937,10 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
             if (open_blk) {
                 const int k = __clz(bm);
                 bm &= ~(0x80000000u >> k);
-                blk = sup * (RT_BVH_SUPER / RT_BVH_BLOCK) + k;
+                blk = sup * (RT_BVH_SUPER / RT_BVH_BLOCK) + (k ^ (int)flip_k);
                 gm = test_boxes(boxes + blk * 12);
                 if (blk == 0) gm &= 0x7fffffffu;  // group 0 has been dealt with
+                gm = bvh_rearrange(gm, flip_g, 3);
             }
         }
         // ---- lanes with an open group sieve its next group of spheres
@@ -1889,7 +1954,7 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
         if (leaf) {
             const int k = __clz(gm);
             gm &= ~(0x80000000u >> k);
-            grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + k;
+            grp = blk * (RT_BVH_BLOCK / RT_CULL_GROUP) + (k ^ (int)flip_g);
             const v4f* g = geom + grp * RT_CULL_GROUP;
             v4f e[RT_CULL_GROUP];
 #pragma unroll
@@ -2010,7 +2075,8 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 
 #define RT_CAM_UNKNOWN (-2)
 // COLD instantiations keep what only the shading of a ray needs in LDS while the ray is traced, not in registers:
-// ten words per lane, cold_w[k * RT_MFMA_MAX_THREADS + thread] (fixed strides: the offsets go into the instructions).
+// ten words per lane, cold_w[k * (most threads of the instantiation) + thread] (fixed strides: the offsets go into the
+// instructions).
 #define RT_COLD_CR 0  // what the path has gathered (Path::cr .. lb)
 #define RT_COLD_CG 1
 #define RT_COLD_CB 2
@@ -2029,7 +2095,9 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 // MODE_ = the sieve (MODE below), + RT_STREAM_SPLIT for the instantiation that shares the frames of heavy tiles.
 #define RT_STREAM_SPLIT 16
 template <bool FUSED, bool RECORD, int MODE_>
-__global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS) rt_stream_kernel(const RtParams P)
+__global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_STREAM_MAX_THREADS,
+                                   (MODE_ & 15) == 4 && !RECORD ? 3 : 1)  // (the per-lane traversal lives on its waves: three per SIMD)
+    rt_stream_kernel(const RtParams P)
 {
     constexpr int MODE = MODE_ & 15;
     constexpr bool SPLIT = (MODE_ & RT_STREAM_SPLIT) != 0 && !RECORD;
@@ -2037,7 +2105,8 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
     constexpr bool CULL = MODE == 2;
     constexpr bool MFMA = MODE == 3 || MODE == 5 || MODE == 7;
     constexpr bool PIPE = MODE != 7;  // 7 = 3 for workgroups of more than RT_STREAM_MAX_THREADS threads (three waves per SIMD)
-    constexpr bool COLD = MODE == 7 && RT_COLD_N > 0;  // ... which has no register to spare over the sieve
+    constexpr bool COLD = MODE == 7 && RT_COLD_N > 0;
+    constexpr int COLD_STRIDE = RT_MFMA_MAX_THREADS;  // ... which has no register to spare over the sieve
     constexpr bool FAR_FRAGS = MODE == 5;  // matrix-core sieve with its sphere-side operands left in global memory
     constexpr bool BVH = MODE == 4;
     constexpr bool BVH_FAR = MODE == 6;  // per-lane traversal out of global memory (nothing staged: P.n_lds == 0)
@@ -2273,19 +2342,19 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
 #endif
         // ---- Trace(): sieve + candidate walk
         if constexpr (COLD) {  // what the path has gathered so far waits in LDS: the shading is the next to look at it
-            cold_w[RT_COLD_CR * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.cr);
-            cold_w[RT_COLD_CG * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.cg);
-            cold_w[RT_COLD_CB * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.cb);
-            cold_w[RT_COLD_LR * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.lr);
-            cold_w[RT_COLD_LG * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.lg);
-            cold_w[RT_COLD_LB * RT_MFMA_MAX_THREADS + threadIdx.x] = __float_as_uint(p.lb);
-            cold_w[RT_COLD_BOUNCE * RT_MFMA_MAX_THREADS + threadIdx.x] = (uint32_t)p.bounce;
-            cold_w[RT_COLD_J * RT_MFMA_MAX_THREADS + threadIdx.x] = (uint32_t)j;
+            cold_w[RT_COLD_CR * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.cr);
+            cold_w[RT_COLD_CG * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.cg);
+            cold_w[RT_COLD_CB * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.cb);
+            cold_w[RT_COLD_LR * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.lr);
+            cold_w[RT_COLD_LG * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.lg);
+            cold_w[RT_COLD_LB * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.lb);
+            cold_w[RT_COLD_BOUNCE * COLD_STRIDE + threadIdx.x] = (uint32_t)p.bounce;
+            cold_w[RT_COLD_J * COLD_STRIDE + threadIdx.x] = (uint32_t)j;
 #if RT_COLD_N > 8
-            cold_w[RT_COLD_PXY * RT_MFMA_MAX_THREADS + threadIdx.x] = pxy;
+            cold_w[RT_COLD_PXY * COLD_STRIDE + threadIdx.x] = pxy;
 #endif
 #if RT_COLD_N > 9
-            cold_w[RT_COLD_NRAYS * RT_MFMA_MAX_THREADS + threadIdx.x] = nrays;
+            cold_w[RT_COLD_NRAYS * COLD_STRIDE + threadIdx.x] = nrays;
 #endif
         }
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
@@ -2443,19 +2512,19 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
 
         // ---- shade
         if constexpr (COLD) {
-            p.cr = __uint_as_float(cold_w[RT_COLD_CR * RT_MFMA_MAX_THREADS + threadIdx.x]);
-            p.cg = __uint_as_float(cold_w[RT_COLD_CG * RT_MFMA_MAX_THREADS + threadIdx.x]);
-            p.cb = __uint_as_float(cold_w[RT_COLD_CB * RT_MFMA_MAX_THREADS + threadIdx.x]);
-            p.lr = __uint_as_float(cold_w[RT_COLD_LR * RT_MFMA_MAX_THREADS + threadIdx.x]);
-            p.lg = __uint_as_float(cold_w[RT_COLD_LG * RT_MFMA_MAX_THREADS + threadIdx.x]);
-            p.lb = __uint_as_float(cold_w[RT_COLD_LB * RT_MFMA_MAX_THREADS + threadIdx.x]);
-            p.bounce = (int)cold_w[RT_COLD_BOUNCE * RT_MFMA_MAX_THREADS + threadIdx.x];
-            j = (int)cold_w[RT_COLD_J * RT_MFMA_MAX_THREADS + threadIdx.x];
+            p.cr = __uint_as_float(cold_w[RT_COLD_CR * COLD_STRIDE + threadIdx.x]);
+            p.cg = __uint_as_float(cold_w[RT_COLD_CG * COLD_STRIDE + threadIdx.x]);
+            p.cb = __uint_as_float(cold_w[RT_COLD_CB * COLD_STRIDE + threadIdx.x]);
+            p.lr = __uint_as_float(cold_w[RT_COLD_LR * COLD_STRIDE + threadIdx.x]);
+            p.lg = __uint_as_float(cold_w[RT_COLD_LG * COLD_STRIDE + threadIdx.x]);
+            p.lb = __uint_as_float(cold_w[RT_COLD_LB * COLD_STRIDE + threadIdx.x]);
+            p.bounce = (int)cold_w[RT_COLD_BOUNCE * COLD_STRIDE + threadIdx.x];
+            j = (int)cold_w[RT_COLD_J * COLD_STRIDE + threadIdx.x];
 #if RT_COLD_N > 8
-            pxy = cold_w[RT_COLD_PXY * RT_MFMA_MAX_THREADS + threadIdx.x];
+            pxy = cold_w[RT_COLD_PXY * COLD_STRIDE + threadIdx.x];
 #endif
 #if RT_COLD_N > 9
-            nrays = cold_w[RT_COLD_NRAYS * RT_MFMA_MAX_THREADS + threadIdx.x];
+            nrays = cold_w[RT_COLD_NRAYS * COLD_STRIDE + threadIdx.x];
 #endif
         }
         if (tracing) {
