@@ -658,7 +658,11 @@ int use_culled(rt_context* c, RtParams* P, bool* on, bool force = false, int max
     P->boxes = c->d_boxes;
     P->n_bounds = (P->n_pad / RT_CULL_GROUP + 63) / 64 * 64;
     P->n_block_boxes = block_boxes(P->n_pad);
-    P->kd_axes = c->kd_axes;
+    for (int a = 0; a < 3; a++) {
+        P->kd_flip[a] = 0u;
+        for (int k = 0; k < 16; k++)
+            if (((c->kd_axes >> (2 * k)) & 3u) == (unsigned)a) P->kd_flip[a] |= 1u << k;
+    }
     P->perm = c->d_perm;
     *on = true;
     return RT_OK;

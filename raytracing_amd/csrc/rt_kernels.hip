@@ -1651,16 +1651,12 @@ __device__ __forceinline__ uint32_t bvh_rearrange(uint32_t m, uint32_t f, int le
     return m;
 }
 
-// The bits of a slot number whose split a ray crosses from the higher coordinates to the lower (RtParams::kd_axes):
-// bit k of the result stands for bit 3 + k of the slot number; n_bits of them (wave-uniform).
-__device__ __forceinline__ uint32_t bvh_flip_bits(const Path& p, uint32_t kd_axes, int n_bits)
+// The bits of a slot number whose split a ray crosses from the higher coordinates to the lower: bit k of the result
+// stands for bit 3 + k of the slot number; RtParams::kd_flip[a] holds the bits whose split is along axis a.
+__device__ __forceinline__ uint32_t bvh_flip_bits(const Path& p, const RtParams& P, int n_bits)
 {
-    const uint32_t neg = (p.dx < 0.0f ? 1u : 0u) | (p.dy < 0.0f ? 2u : 0u) | (p.dz < 0.0f ? 4u : 0u);
-    uint32_t flip = 0u;
-#pragma unroll
-    for (int k = 0; k < 13; k++)
-        if (k < n_bits) flip |= ((neg >> ((kd_axes >> (2 * k)) & 3u)) & 1u) << k;
-    return flip;
+    const uint32_t flip = (p.dx < 0.0f ? P.kd_flip[0] : 0u) | (p.dy < 0.0f ? P.kd_flip[1] : 0u) | (p.dz < 0.0f ? P.kd_flip[2] : 0u);
+    return flip & ((1u << n_bits) - 1u);
 }
 
 // (The traversal is a chain of dependent LDS gathers and gains from every wave it can get: 13.9 /
@@ -1734,7 +1730,7 @@ __device__ __forceinline__ void trace_bvh(const Path& p, float a, bool alive, co
     // 65 536 2.29 / 1.99, 1000 spheres 8.5 / 7.1, 484 spheres on a plane 4.79 / 4.26 (4.11 with one bit for the whole
     // list, by the sign of dx + dy + dz: there the ~90 instructions a pass that the bits cost outweigh what they add).
     const int levels = nblk > 32 ? 6 : nblk > 16 ? 5 : nblk > 8 ? 4 : 3;  // bits that number this scene's blocks
-    const uint32_t flip = bvh_flip_bits(p, P.kd_axes, 3 + levels);
+    const uint32_t flip = bvh_flip_bits(p, P, 3 + levels);
     const uint32_t flip_g = flip & 7u, flip_b = flip >> 3;  // of the group within its block, of the block
     // the masks of the blocks, bit (31 - n) for block n, rearranged so that bit (31 - m) stands for block m ^ flip_b
     auto rearrange = [](uint32_t m, uint32_t f, int levels) { return bvh_rearrange(m, f, levels); };
@@ -1892,7 +1888,7 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
     // nearer nodes first (see trace_bvh): groups of a block, blocks of a superblock, superblocks
     int sup_bits = 0;
     while ((1 << sup_bits) < nsb) sup_bits++;
-    const uint32_t flip = bvh_flip_bits(p, P.kd_axes, 6 + sup_bits);
+    const uint32_t flip = bvh_flip_bits(p, P, 6 + sup_bits);
     const uint32_t flip_g = flip & 7u, flip_k = (flip >> 3) & 7u, flip_s = flip >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) sm[w] = bvh_rearrange(sm[w], flip_s & 31u, sup_bits);

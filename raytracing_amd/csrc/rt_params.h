@@ -130,8 +130,8 @@ struct RtParams {
                                  // 64 slots, then of the superblocks of 512 slots; centre and half-width
                                  // pair-packed per axis, 3 float4 per pair of entries
     int n_block_boxes;           // block entries in `boxes` (a multiple of 8, at least RT_BVH_BLOCKS)
-    unsigned kd_axes;            // per-lane traversal: two bits per bit 3, 4, ... of a slot number of the sorted list: the axis
-                                 // (0 x, 1 y, 2 z) along which the two halves that differ in that bit were split, lower half first
+    unsigned kd_flip[3];         // per-lane traversal: per axis (x, y, z) the bits 3, 4, ... of a slot number of the sorted list (as
+                                 // bits 0, 1, ... here) whose two halves were split along that axis, lower half first
     const int* perm;             // sorted slot -> index in `spheres` (n_pad entries)
     int sg_wide;                 // != 0: candidate walks every RT_SG_CHUNKS_WIDE chunks instead of every RT_SG_CHUNKS
                                  // (brute-force kernels only; the masks in LDS are sized to match)
