@@ -775,6 +775,32 @@ def test_full_size_4k_stream_equals_tile(rt, rtiow_scene, pname, profile):
         assert np.array_equal(c_stream3[1200:1216], ccol[1200:1216])
 
 
+@pytest.mark.parametrize("stride,clear", [(1, 0), (3, 1), (2, 2)], ids=["reference", "stride3_clear_first", "stride2_clear_never"])
+def test_runs_of_frames_under_the_schedules_of_the_sample_split(rt, rtiow_scene, stride, clear):
+    """The frame schedules a sample split over several GPUs uses (every stride-th frame number; the first
+    frame of a dispatch clears, or none does) through the stream kernel's runs of frames: three dispatches
+    against the tile kernel, whole image."""
+    w, h = 1920, 1080
+    out = {}
+    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
+        with rt.Renderer(w, h) as r:
+            r.set_kernel(kernel)
+            r.set_frame_schedule(stride, clear)
+            r.upload_spheres(rtiow_scene.spheres)
+            r.write_accum(np.full((h, w, 4), 0.5, np.float32))
+            for k in range(3):
+                u = rtiow_scene.camera.copy()
+                u["frameCount"][0] = 1 + 6 * stride * k  # reference schedule: the first dispatch clears at frame 1
+                r.set_uniforms(u)
+                r.dispatch(6)
+                if kernel == rt.KERNEL_STREAM and k > 0:
+                    info = r.split_info()
+                    assert info["ways"] == 6 and info["frames"] == 1 and info["tiles"] > 0, info
+            out[kernel] = (r.read_accum(), r.read_color(), r.counters()["rays"])
+    a, b = out[rt.KERNEL_STREAM], out[rt.KERNEL_TILE]
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
 @pytest.mark.parametrize("pname,profile", PROFILES)
 def test_frames_of_heavy_tiles_in_runs_stream_kernel(rt, rtiow_scene, pname, profile):
     """1920x1080, ~500 spheres, 8 frames a dispatch: ten tiles per wave of the stream kernel, so from the
