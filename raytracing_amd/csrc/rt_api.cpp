@@ -1756,6 +1756,13 @@ int rt_get_counters(rt_context* c, rt_counters* out)
             w[0] += q[0]; w[1] += q[1]; w[2] = std::max(w[2], q[2]); w[3] = std::max(w[3], q[3]);
             w[4] = std::max(w[4], q[4]); w[5] += q[5];
         }
+        unsigned long long sp[2] = {0, 0};
+        for (unsigned i = 0; i < RT_RAY_SLOTS; i++) {
+            sp[0] += slots[i * RT_RAY_SLOT_STRIDE + 14];
+            sp[1] += slots[i * RT_RAY_SLOT_STRIDE + 15];
+        }
+        fprintf(stderr, "span fetches: %llu, %.0f cycles each, %.1f %% of the refill\n", sp[1], (double)sp[0] / std::max(1ull, sp[1]),
+                100.0 * sp[0] / std::max(1ull, t[0]));
         const double nw = (double)std::max(1ull, w[5]);
         fprintf(stderr, "wave lifetime (us): mean %.1f, shortest %.1f, longest %.1f; after the queues ran dry: mean %.1f, longest %.1f\n",
                 w[0] * 0.01 / nw, ~w[3] * 0.01, w[2] * 0.01, w[1] * 0.01 / nw, w[4] * 0.01);

@@ -2207,7 +2207,7 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
 #ifdef RT_PHASE_TIMERS
     // experiment: shader-clock cycles this wave spends in each phase of its loop, added to words
     // 3..7 of its counter slot (refill, sieve, walk, shade, iterations)
-    unsigned long long t_refill = 0, t_sieve = 0, t_walk = 0, t_shade = 0, n_iter = 0;
+    unsigned long long t_refill = 0, t_sieve = 0, t_walk = 0, t_shade = 0, n_iter = 0, t_span = 0, n_span = 0;
     unsigned long long t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock
     unsigned long long rt_exhausted = 0;
@@ -2225,6 +2225,10 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
         unsigned long long freem = __ballot(!alive);
         while (freem != 0ull && !exhausted) {
             if (avail == 0ull) {
+#ifdef RT_PHASE_TIMERS
+                const unsigned long long t_span0 = __builtin_amdgcn_s_memtime();
+                n_span++;
+#endif
                 // spans q, q + RT_QUEUES, ... belong to queue q
                 const uint32_t k = __builtin_amdgcn_readfirstlane(have_ahead ? ahead : ask(queue));
                 have_ahead = false;
@@ -2259,6 +2263,9 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)live);
                     }
                 }
+#ifdef RT_PHASE_TIMERS
+                t_span += __builtin_amdgcn_s_memtime() - t_span0;
+#endif
                 if (avail == 0ull) continue;
             }
             // free lane number r takes the r-th pixel left: lane p, where the r-th set bit of avail is, sends p to
@@ -2556,6 +2563,8 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
         atomicMax(slot + 11, ~(rt_end - rt_start));
         atomicMax(slot + 12, rt_end - rt_exhausted);
         atomicAdd(slot + 13, 1ull);
+        atomicAdd(slot + 14, t_span);
+        atomicAdd(slot + 15, n_span);
     }
 #endif
     // (the camera rays served by P.cam_hits are a path each: the host counts them)
