@@ -686,8 +686,10 @@ int small_scene_kernel()
 
 int env_int(const char* name, int fallback) { return rt_dev_knob(name, fallback); }
 
-// Tiles in descending order of their cost in an earlier dispatch of the same region, for the
-// kernels that hand out whole tiles or spans of pixels (rt_tile_order_kernel): fills P.tile_order
+// Tiles in descending order of their cost in an earlier dispatch of the same region (the lite kernel, which hands
+// out whole tiles: the tile's rays; the stream kernel, whose lanes take single pixels: the most rays any pixel of the
+// tile took, zero_cost below), for the kernels that hand out whole tiles or spans of pixels
+// (rt_tile_order_kernel; nwaves and heavy_den: how many of the leading tiles it counts as heavy): fills P.tile_order
 // when an order is at hand, and P.tile_cost (where this dispatch leaves its costs) when the next
 // dispatch will want to sort.  An order serves 8 dispatches: the sort is one workgroup's work
 // (measured under rocprofv3: 60 us for the 32 400 tiles of a 1080p image, 215 us for 4K) and what

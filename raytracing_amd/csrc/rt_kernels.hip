@@ -975,11 +975,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
     }
     if (!valid) return;
     // (every camera ray of this kernel is traced against its tile's list: the host counts them, a path each)
-#ifdef RT_LITE_NO_COUNT
-    const unsigned long long wave_rays = nrays;
-#else
     const unsigned long long wave_rays = add_rays(P, nrays, tile);
-#endif
     // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
     if (P.tile_cost != nullptr && lane == 0 && run <= 0)
         P.tile_cost[tile] = (uint32_t)min(wave_rays * (run == 0 ? ways : 1u), 0xffffffffull);
@@ -2084,9 +2080,6 @@ __device__ __forceinline__ void trace_bvh_far(const Path& p, float a, bool alive
 #define RT_COLD_PXY 8
 #define RT_COLD_NRAYS 9
 #define RT_COLD_WORDS 10
-#ifndef RT_COLD_N
-#define RT_COLD_N 10
-#endif
 
 // MODE_ = the sieve (MODE below), + RT_STREAM_SPLIT for the instantiation that shares the frames of heavy tiles.
 #define RT_STREAM_SPLIT 16
@@ -2101,7 +2094,7 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
     constexpr bool CULL = MODE == 2;
     constexpr bool MFMA = MODE == 3 || MODE == 5 || MODE == 7;
     constexpr bool PIPE = MODE != 7;  // 7 = 3 for workgroups of more than RT_STREAM_MAX_THREADS threads (three waves per SIMD)
-    constexpr bool COLD = MODE == 7 && RT_COLD_N > 0;
+    constexpr bool COLD = MODE == 7;
     constexpr int COLD_STRIDE = RT_MFMA_MAX_THREADS;  // ... which has no register to spare over the sieve
     constexpr bool FAR_FRAGS = MODE == 5;  // matrix-core sieve with its sphere-side operands left in global memory
     constexpr bool BVH = MODE == 4;
@@ -2353,12 +2346,8 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
             cold_w[RT_COLD_LB * COLD_STRIDE + threadIdx.x] = __float_as_uint(p.lb);
             cold_w[RT_COLD_BOUNCE * COLD_STRIDE + threadIdx.x] = (uint32_t)p.bounce;
             cold_w[RT_COLD_J * COLD_STRIDE + threadIdx.x] = (uint32_t)j;
-#if RT_COLD_N > 8
             cold_w[RT_COLD_PXY * COLD_STRIDE + threadIdx.x] = pxy;
-#endif
-#if RT_COLD_N > 9
             cold_w[RT_COLD_NRAYS * COLD_STRIDE + threadIdx.x] = nrays;
-#endif
         }
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
@@ -2523,12 +2512,8 @@ __global__ void __launch_bounds__((MODE_ & 15) == 7 ? RT_MFMA_MAX_THREADS : RT_S
             p.lb = __uint_as_float(cold_w[RT_COLD_LB * COLD_STRIDE + threadIdx.x]);
             p.bounce = (int)cold_w[RT_COLD_BOUNCE * COLD_STRIDE + threadIdx.x];
             j = (int)cold_w[RT_COLD_J * COLD_STRIDE + threadIdx.x];
-#if RT_COLD_N > 8
             pxy = cold_w[RT_COLD_PXY * COLD_STRIDE + threadIdx.x];
-#endif
-#if RT_COLD_N > 9
             nrays = cold_w[RT_COLD_NRAYS * COLD_STRIDE + threadIdx.x];
-#endif
         }
         if (tracing) {
             // a camera ray that went through the sieve (no list for its tile): its hit serves the pixel's other frames
@@ -2929,10 +2914,7 @@ void rt_bvh_step_counts(unsigned long long out[4])
 }
 #endif
 
-#ifndef RT_LITE_LDS_EXTRA
-#define RT_LITE_LDS_EXTRA 0
-#endif
-size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4) + RT_LITE_LDS_EXTRA; }
+size_t rt_lite_lds_bytes() { return 3 * 2 * RT_CHUNK * sizeof(float4); }
 
 // LDS for the lights that the runs of the split tiles of a workgroup of `waves` waves hand to their first run.
 size_t rt_lite_handover_bytes(unsigned waves, int ways, int split_frames)
