@@ -775,17 +775,19 @@ def test_full_size_4k_stream_equals_tile(rt, rtiow_scene, pname, profile):
         assert np.array_equal(c_stream3[1200:1216], ccol[1200:1216])
 
 
-@pytest.mark.parametrize("stride,clear", [(1, 0), (3, 1), (2, 2)], ids=["reference", "stride3_clear_first", "stride2_clear_never"])
-def test_runs_of_frames_under_the_schedules_of_the_sample_split(rt, rtiow_scene, stride, clear):
+@pytest.mark.parametrize("stride,clear,shortcuts", [(1, 0, True), (3, 1, True), (2, 2, True), (1, 0, False), (2, 1, False)],
+                         ids=["reference", "stride3_clear_first", "stride2_clear_never", "no_shortcuts", "no_shortcuts_stride2"])
+def test_runs_of_frames_under_the_schedules_of_the_sample_split(rt, rtiow_scene, stride, clear, shortcuts):
     """The frame schedules a sample split over several GPUs uses (every stride-th frame number; the first
-    frame of a dispatch clears, or none does) through the stream kernel's runs of frames: three dispatches
-    against the tile kernel, whole image."""
+    frame of a dispatch clears, or none does) through the stream kernel's runs of frames, with and without the
+    camera-ray shortcuts: three dispatches against the tile kernel, whole image."""
     w, h = 1920, 1080
     out = {}
     for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
         with rt.Renderer(w, h) as r:
             r.set_kernel(kernel)
             r.set_frame_schedule(stride, clear)
+            r.set_camera_shortcuts(shortcuts)  # off: every camera ray goes through the sieve, sky pixels end in their lanes
             r.upload_spheres(rtiow_scene.spheres)
             r.write_accum(np.full((h, w, 4), 0.5, np.float32))
             for k in range(3):
