@@ -489,6 +489,42 @@ def test_shared_frames_under_the_other_clear_modes(rt, default_scene, clear):
             assert np.array_equal(r.read_color(), ccol), k
 
 
+def test_a_camera_that_sees_only_sky_and_one_that_sees_one_sphere(rt, rtiow_scene):
+    """No tile of the image has a pixel for the stream kernel (every wave finds every span empty and the
+    queues dry), then a view from far above in which few tiles have: the bulk kernel for the sky pixels does all
+    or most of the work.  Three accumulating dispatches each (1920x1080 x 4 frames: with an order of the tiles
+    from the second on) against the oracle's sky value and the tile kernel."""
+    w, h = 1920, 1080
+    up = rtiow_scene.camera.copy()
+    up["camera_position"][0] = np.float32([0.0, 30.0, 0.0])
+    up["camera_forward"][0] = np.float32([0.0, 1.0, 0.0])     # straight up, away from every sphere
+    up["camera_right"][0] = np.float32([1.0, 0.0, 0.0])
+    up["camera_up"][0] = np.float32([0.0, 0.0, -1.0])
+    far = rtiow_scene.camera.copy()
+    far["camera_position"][0] = np.float32([0.0, 4000.0, 0.0])  # high above: the scene is a disc in the middle of the image
+    far["camera_forward"][0] = np.float32([0.0, -1.0, 0.0])
+    far["camera_right"][0] = np.float32([1.0, 0.0, 0.0])
+    far["camera_up"][0] = np.float32([0.0, 0.0, 1.0])
+    for name, cam in (("up", up), ("far", far)):
+        out = {}
+        for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
+            with rt.Renderer(w, h) as r:
+                r.set_kernel(kernel)
+                r.upload_spheres(rtiow_scene.spheres)
+                for k in range(3):
+                    u = cam.copy()
+                    u["frameCount"][0] = 1 + 4 * k
+                    r.set_uniforms(u)
+                    r.dispatch(4)
+                out[kernel] = (r.read_accum(), r.read_color(), r.counters()["rays"])
+        a, b = out[rt.KERNEL_STREAM], out[rt.KERNEL_TILE]
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2], name
+        if name == "up":
+            assert a[2] == w * h * 12  # a ray a path: nothing was hit
+        else:
+            assert w * h * 12 < a[2] < w * h * 12 * 1.2  # the ground sphere and the dot of small ones on it
+
+
 def test_camera_hits_follow_camera_scene_and_size(rt, rtiow_scene):
     """The stream kernel finds the hit of every pixel's camera ray once (a cone test per tile, then the
     literal test of the few spheres left) and keeps it while camera, image and spheres stay.  One
