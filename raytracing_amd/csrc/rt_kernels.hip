@@ -975,10 +975,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
     }
     if (!valid) return;
     // (every camera ray of this kernel is traced against its tile's list: the host counts them, a path each)
-    const unsigned long long wave_rays = add_rays(P, nrays, tile);
-    // (a split tile's cost: its first run's rays times the runs -- near enough for an order)
+    (void)add_rays(P, nrays, tile);
+    // The tile's cost for the next order: the rays of its longest lane -- the lanes of a wave go through their frames
+    // independently, so the wave lasts as long as the pixel that bounces most (by the sum of the lanes' rays, which is
+    // what the order went by before: 1280x720 x 64 frames 0.635 -> 0.522 ms, 1920x1080 x 64 frames 1.148 -> 1.065 ms).
+    // (A split tile's: its first run's times the runs, near enough for an order.)
+    const uint32_t longest = wave_max_u32(nrays);
     if (P.tile_cost != nullptr && lane == 0 && run <= 0)
-        P.tile_cost[tile] = (uint32_t)min(wave_rays * (run == 0 ? ways : 1u), 0xffffffffull);
+        P.tile_cost[tile] = (uint32_t)min((unsigned long long)longest * (run == 0 ? ways : 1u), 0xffffffffull);
 }
 
 // The pixels of the tiles that rt_lite_kernel traced in split_ways runs of frames: the first run left

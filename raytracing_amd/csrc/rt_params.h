@@ -160,8 +160,9 @@ struct RtParams {
                                  // the word at split_count
     float4* split_lights;        // the light of every path of the runs after a tile's first:
                                  // [tile of the order][run - 1][frame of the run][pixel of the tile]
-    uint32_t* tile_cost;         // rays of each tile in this dispatch are left here (may be null): stored by the
-                                 // lite kernel, added pixel by pixel by the stream kernel (zeroed before the launch)
+    uint32_t* tile_cost;         // what each tile cost in this dispatch is left here (may be null): the lite kernel stores the
+                                 // rays of the tile's longest lane, the stream kernel adds the tile's rays pixel by pixel
+                                 // (zeroed before the launch)
     uint32_t* tile_chain;        // stream kernel, with tile_cost: the most rays a pixel of each tile took (zeroed before the launch)
     float4* accum;               // width*height rgba32f
     uint32_t* color;             // width*height rgba8
