@@ -800,11 +800,15 @@ int use_camera_hits(rt_context* c, RtParams& P, bool fused)
 // a 1.45 ms dispatch at 1280x720 x 64 frames (depth 8), whatever else the chip does meanwhile.
 // Measured, runs per tile 2 / 4 / 8 (Grays/s): 640x360 x 64 frames 27 / 49 / 71 (unsplit 14), 1280x720 x 64
 // (depth 8) 89 / 99 / 97 (53), 1920x1080 x 64 112 / 107 / 104 (96), 3840x2160 x 16 114 / 108 / 97 -- the fewer
-// tiles a wave slot of the chip gets, the more runs; a quarter of the tiles split is no gain at 1080p, all
-// of them less than half.  Does nothing without an order or when the lights cannot be allocated.
+// tiles a wave slot of the chip gets, the more runs.  How many tiles: with the order by a tile's longest lane (which is
+// what a wave lasts by), a third of them up to five tiles a wave slot, a sixteenth beyond -- measured at 64 frames,
+// one tile in 2 / 3 / 4 / 8 / 16 / 32 (ms): 640x360 0.227 / 0.228 / 0.33 / 0.31 / 0.59 / 0.86, 1280x720 (depth 8) 0.524 /
+// 0.511 / 0.59 / 0.59 / 0.61 / 0.83, 1920x1080 1.06 / 1.04 / 1.06 / 1.02 / 1.01 / 1.11, 2560x1440 1.77 / 1.73 / 1.71 /
+// 1.69 / 1.67 / 1.68, 3840x2160 x 16 frames 1.08 / 1.06 / 1.04 / 1.03 / 1.03 / 1.02.  Does nothing without an order or
+// when the lights cannot be allocated.
 void use_frame_split(rt_context* c, RtParams& P)
 {
-    static const int share = env_int("RT_DEBUG_SPLIT_SHARE", 2);  // development knob: one tile in `share`; 0 = none
+    static const int share_env = env_int("RT_DEBUG_SPLIT_SHARE", -1);  // development knob: one tile in N; 0 = none; -1: as above
     static const int ways_env = env_int("RT_DEBUG_SPLIT_WAYS", 0);  // development knob: 2, 4 or 8
     P.split_tiles = 0;
     P.split_ways = 0;
@@ -813,9 +817,10 @@ void use_frame_split(rt_context* c, RtParams& P)
     P.split_lights = nullptr;
     P.split_count = nullptr;
     P.split_units = nullptr;
-    if (share <= 0 || P.tile_order == nullptr || P.n_frames < 16) return;
+    if (share_env == 0 || P.tile_order == nullptr || P.n_frames < 16) return;
     const unsigned ntiles = P.total_pixels / 64u;
     const unsigned slots = 20u * (unsigned)c->cu_count;  // waves of this kernel that the chip holds at a time
+    const int share = share_env > 0 ? share_env : ntiles < 5u * slots ? 3 : 16;
     int ways = 2 * ntiles < 3 * slots ? 8 : 2 * ntiles < 9 * slots ? 4 : 2;
     // two runs whose lights would have to be parked in device memory, where four runs' lights fit in LDS (below):
     // four, up to images of 20 tiles per wave slot (measured at 64 frames, 2 ways parked against 4 through LDS:
