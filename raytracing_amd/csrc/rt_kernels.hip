@@ -854,6 +854,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
             path_reset(p, P, d0x, d0y, d0z);                                                                    \
         }                                                                                                       \
     }
+#ifdef RT_COUNT_PASSES
+    unsigned lite_passes = 0, lite_pass_lanes = 0;  // experiment: passes of this wave, lanes with a ray in them
+#endif
     for (;;) {
         // ---- a lane at the start of a frame whose camera hit is known shades it and joins the others with its
         // first bounce ray: after the wave's first pass no lane waits for another, each runs through its frames at
@@ -882,6 +885,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
         }
         const unsigned long long alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
+#ifdef RT_COUNT_PASSES
+        lite_passes++;
+        lite_pass_lanes += (unsigned)__popcll(alive_mask);
+#endif
         const float a = dot3<FUSED>(p.dx, p.dy, p.dz, p.dx, p.dy, p.dz);
         float best = RT_FLT_MAX;
         int idx = -1;
@@ -976,6 +983,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MANY 
     if (!valid) return;
     // (every camera ray of this kernel is traced against its tile's list: the host counts them, a path each)
     (void)add_rays(P, nrays, tile);
+#ifdef RT_COUNT_PASSES
+    if (lane == 0) atomicAdd(P.rays + (tile % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 1, (unsigned long long)lite_passes);
+    if (lane == 1) atomicAdd(P.rays + (tile % RT_RAY_SLOTS) * RT_RAY_SLOT_STRIDE + 3, (unsigned long long)lite_pass_lanes);
+#endif
     // The tile's cost for the next order: the rays of its longest lane -- the lanes of a wave go through their frames
     // independently, so the wave lasts as long as the pixel that bounces most (by the sum of the lanes' rays, which is
     // what the order went by before: 1280x720 x 64 frames 0.635 -> 0.522 ms, 1920x1080 x 64 frames 1.148 -> 1.065 ms).
