@@ -489,6 +489,34 @@ def test_shared_frames_under_the_other_clear_modes(rt, default_scene, clear):
             assert np.array_equal(r.read_color(), ccol), k
 
 
+def test_runs_of_frames_follow_a_changing_frame_count(rt, rtiow_scene):
+    """One order of the tiles serves eight dispatches; the list of work units made of it depends on the
+    frames of a dispatch (runs per heavy tile, frames per run) and is made again when that changes.  A
+    sequence of dispatches of 8, 8, 5, 12, 3, 2, 1 and 9 frames (those of two frames and of one take their tiles in image order)
+    against the tile kernel, whole image, and the shapes of the split as reported."""
+    w, h = 1920, 1080
+    seq = (8, 8, 5, 12, 3, 2, 1, 9)
+    want = {8: (8, 1), 5: (5, 1), 12: (6, 2), 3: (3, 1), 9: (5, 2)}  # frames -> (runs, frames per run); 2 frames: below 4 M paths
+    out = {}
+    for kernel in (rt.KERNEL_STREAM, rt.KERNEL_TILE):
+        with rt.Renderer(w, h) as r:
+            r.set_kernel(kernel)
+            r.upload_spheres(rtiow_scene.spheres)
+            first = 1
+            for k, n in enumerate(seq):
+                u = rtiow_scene.camera.copy()
+                u["frameCount"][0] = first
+                r.set_uniforms(u)
+                r.dispatch(n)
+                first += n
+                if kernel == rt.KERNEL_STREAM and k > 0 and n in want:
+                    info = r.split_info()
+                    assert (info["ways"], info["frames"]) == want[n] and info["tiles"] > 0, (n, info)
+            out[kernel] = (r.read_accum(), r.read_color(), r.counters()["rays"])
+    a, b = out[rt.KERNEL_STREAM], out[rt.KERNEL_TILE]
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
 def test_a_camera_that_sees_only_sky_and_one_that_sees_one_sphere(rt, rtiow_scene):
     """No tile of the image has a pixel for the stream kernel (every wave finds every span empty and the
     queues dry), then a view from far above in which few tiles have: the bulk kernel for the sky pixels does all
