@@ -26,9 +26,13 @@
 //                    MODE picks the sieve and where its operands come from (scalar cache, LDS,
 //                    matrix-core fragments in LDS or streamed from global memory), or, not brute
 //                    force any more, a spatially sorted list with wave-level group culling or a
-//                    per-lane walk down a hierarchy of bounding spheres (trace_bvh).
+//                    per-lane walk down a hierarchy of boxes, nearer nodes first (trace_bvh).
 //   rt_lite_kernel   at most 64 spheres: one wave per tile, no queues, sieve + walk from LDS,
 //                    lanes run their pixel's frames back to back.
+// and their helpers: rt_camera_hits_kernel (the hit of every pixel's camera ray, once per camera and scene),
+// rt_sky_frames_kernel (all frames of the pixels that see the sky), rt_tile_order_kernel and rt_tile_units_kernel
+// (the tiles by descending cost; the units of work of a dispatch whose heavy tiles are traced in runs of frames),
+// rt_lite_join_kernel (the lights of such runs, added in frame order), rt_resolve_kernel.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
