@@ -952,10 +952,11 @@ int launch(rt_context* c, const RtParams& P_in, bool record)
             // 1920x1080 x 64 frames 2.98 -> 2.47 ms; sorted before every dispatch, 3840x2160 x 8 frames 1.27 -> 1.37 ms.
             // Dispatches of a few frames (the interactive loop: one) end with the tiles that hold a chain of
             // mirror bounces, wherever in the image they are; the chains sit where the geometry puts them, frame
-            // after frame, so there an order serves 128 dispatches and its sort costs next to nothing: 1080p x 1
-            // frame 61.7 -> 56.6-57.6 us (an order for 8 dispatches: 61.7 -> 61.9; for 32: 58.0).
+            // after frame, so there an order serves 512 dispatches and its sort costs next to nothing: 1080p x 1
+            // frame 61.7 -> 56.6-57.6 us with 128 (an order for 8 dispatches: 61.7 -> 61.9; for 32: 58.0); with the
+            // scripted camera of the interactive benchmark 128 / 512 / 2048 dispatches: 43.08 / 42.74 / 43.0 us a frame.
             static const int lpt_min_frames = env_int("RT_DEBUG_LPT_MIN_FRAMES", 1);  // development knob; < 0: never
-            if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false, P.n_frames >= 16 ? 8 : 128);
+            if (lpt_min_frames >= 0) use_tile_order(c, P, P.n_frames >= lpt_min_frames, false, P.n_frames >= 16 ? 8 : 512);
             use_frame_split(c, P);
             P.cam_reuse = c->camera_shortcuts;  // the bundled camera pass of every frame
             e = rt_launch_lite(P, fused, threads, c->stream);
